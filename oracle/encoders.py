@@ -1,0 +1,171 @@
+"""Functional fp32 restatement of the reference encoders (TEST INFRASTRUCTURE — see __init__).
+
+All functions take a plain dict `sd` of tensors keyed by the reference's state_dict names and return a dict
+with the fields of the reference's output dataclasses (model/component/output.py:16-35).
+`cap` (optional dict) receives intermediates for kernel-level parity tests.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, sd, prefix, eps=1e-5):
+    # reference _common.py:14-20 (fp32 LayerNorm, eps 1e-5) / nn.LayerNorm in weight_share_model.py:239
+    return F.layer_norm(x.float(), (x.shape[-1],), sd[prefix + '.weight'], sd[prefix + '.bias'], eps)
+
+
+def quick_gelu(x):
+    # reference _common.py:23-25
+    return x * torch.sigmoid(1.702 * x)
+
+
+def _teacher_attention(h, sd, p, heads, mask, cap, tag):
+    # reference _common.py:51-95
+    B, N, D = h.shape
+    hd = D // heads
+    qkv = F.linear(h, sd[p + 'in_proj_weight'], sd[p + 'in_proj_bias'])
+    q, k, v = qkv.chunk(3, dim=-1)
+    sp = lambda t: t.view(B, N, heads, hd).permute(0, 2, 1, 3)
+    q, k, v = sp(q), sp(k), sp(v)
+    scores = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if mask is not None:
+        scores = scores + mask
+    probs = scores.softmax(dim=-1)
+    ctx = (probs @ v).permute(0, 2, 1, 3).reshape(B, N, D)
+    if cap is not None:
+        cap[tag + '.ctx'] = ctx
+    return F.linear(ctx, sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'])
+
+
+def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, need_rep=False):
+    # reference _common.py:116-127 (block), :143-167 (stack)
+    reps = []
+    for i in range(layers):
+        p = f'{prefix}transformer.resblocks.{i}.'
+        x = x + _teacher_attention(_ln(x, sd, p + 'ln_1'), sd, p + 'attn.', heads, mask, cap, f'tblock{i}')
+        h = _ln(x, sd, p + 'ln_2')
+        u = quick_gelu(F.linear(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias']))
+        x = x + F.linear(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'])
+        if cap is not None:
+            cap[f'tblock{i}.out'] = x
+        if need_rep and (need_layers is None or i in need_layers):
+            reps.append(x)
+    return x, reps
+
+
+def teacher_image_forward(sd, image, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None):
+    """reference _common.py:188-221 (VisionTransformer.forward) behind image_encoder.py:50-65."""
+    w = sd['visual.conv1.weight']
+    width, patch = w.shape[0], w.shape[-1]
+    layers = 1 + max(int(k.split('.')[3]) for k in sd if k.startswith('visual.transformer.resblocks.'))
+    heads = heads or width // 64            # reference utils.py:126 (heads = width*32//64 // 32 ... = width//64)
+    x = F.conv2d(image, w, stride=patch)                            # :196
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)      # :197-198
+    cls = sd['visual.class_embedding'] + torch.zeros(x.shape[0], 1, width)
+    x = torch.cat([cls, x], dim=1) + sd['visual.positional_embedding']   # :199-202
+    emb = x if need_emb else None
+    x = _ln(x, sd, 'visual.ln_pre')                                  # :208
+    x, reps = _teacher_blocks(x, sd, 'visual.', layers, heads, None, cap, need_layers, need_rep)
+    x = _ln(x, sd, 'visual.ln_post') @ sd['visual.proj']             # :210-213
+    return dict(last_representation=x[:, 0, :], last_layer_output=x, representations=reps, embedding=emb)
+
+
+def causal_mask(n):
+    # reference text_encoder.py:54-60
+    return torch.full((n, n), float('-inf')).triu_(1)
+
+
+def teacher_text_forward(sd, text, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None):
+    """reference text_encoder.py:62-92 (TextEncoder.encode_text)."""
+    width = sd['positional_embedding'].shape[1]
+    layers = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('transformer.resblocks.'))
+    heads = heads or width // 64            # reference utils.py:94
+    x = sd['token_embedding.weight'][text] + sd['positional_embedding']     # :65-66
+    emb = x if need_emb else None
+    x, reps = _teacher_blocks(x, sd, '', layers, heads, causal_mask(text.shape[1]), cap, need_layers, need_rep)
+    x = _ln(x, sd, 'ln_final') @ sd['text_projection']                      # :69,72
+    pick = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]                 # :86
+    return dict(last_representation=pick, last_layer_output=x, representations=reps, embedding=emb)
+
+
+def _mini_attention(h, sd, p, r, heads, use_transform, cap, tag):
+    # reference weight_share_model.py:88-140 (MiniAttention.forward), rpe disabled (rpe_config: null)
+    B, N, C = h.shape
+    hd = C // heads
+    qkv = F.linear(h, sd[p + 'qkv.weight'], sd.get(p + 'qkv.bias'))
+    qkv = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]                   # :101 (q *= scale)
+    attn = q @ k.transpose(-2, -1)                                  # :103
+    if cap is not None:
+        cap[tag + '.scores'] = attn
+    if use_transform:
+        wl = sd[p + f'conv_l.instances.{r}.weight'].reshape(heads, heads)
+        attn = torch.einsum('gh,bhij->bgij', wl, attn)             # :114-115 (1x1 conv over the head channel)
+    attn = attn.softmax(dim=-1)                                     # :117
+    if cap is not None:
+        cap[tag + '.probs'] = attn
+    if use_transform:
+        ww = sd[p + f'conv_w.instances.{r}.weight'].reshape(heads, heads)
+        attn = torch.einsum('gh,bhij->bgij', ww, attn)             # :120-121
+    if cap is not None:
+        cap[tag + '.mixed'] = attn
+    out = (attn @ v).transpose(1, 2).reshape(B, N, C)               # :125,131
+    if cap is not None:
+        cap[tag + '.ctx'] = out
+    return F.linear(out, sd[p + 'proj.weight'], sd[p + 'proj.bias'])  # :132
+
+
+def _student_blocks(x, sd, heads, repeats, use_transform, cap, need_rep=False):
+    # reference weight_share_model.py:199-218 (RepeatedMiniBlock) and :179-185 (MiniBlock)
+    n_blocks = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+    reps = []
+    for i in range(n_blocks):
+        p = f'blocks.{i}.block.'
+        for r in range(repeats):
+            tag = f'sblock{i}.{r}'
+            h = _ln(x, sd, p + f'norm1.instances.{r}')
+            x = x + _mini_attention(h, sd, p + 'attn.', r, heads, use_transform, cap, tag)
+            h = _ln(x, sd, p + f'norm2.instances.{r}')
+            u = F.gelu(F.linear(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias']))    # timm Mlp, exact erf GELU
+            x = x + F.linear(u, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'])
+            if cap is not None:
+                cap[tag + '.out'] = x
+            if need_rep:
+                reps.append(x)
+    return x, reps
+
+
+def student_image_forward(sd, image, num_heads, repeated_times=2, use_transform=True, need_rep=False, cap=None):
+    """reference weight_share_model.py:336-372 (RepeatVisionTransformer.forward_features)."""
+    w = sd['patch_embed.proj.weight']
+    patch = w.shape[-1]
+    x = F.conv2d(image, w, sd['patch_embed.proj.bias'], stride=patch).flatten(2).transpose(1, 2)   # :344 (timm PatchEmbed)
+    x = torch.cat((sd['cls_token'].expand(x.shape[0], -1, -1), x), dim=1) + sd['pos_embed']        # :346-349
+    emb = x
+    x, reps = _student_blocks(x, sd, num_heads, repeated_times, use_transform, cap, need_rep)
+    x = F.linear(_ln(x, sd, 'norm'), sd['head.weight'], sd['head.bias'])                           # :363-364
+    return dict(last_representation=x[:, 0], last_layer_output=x, representations=reps, embedding=emb)
+
+
+def student_text_forward(sd, text, num_heads, repeated_times=2, use_transform=True, need_rep=False, cap=None):
+    """reference weight_share_model.py:482-512 (RepeatTextTransformer.forward_features); no attention mask."""
+    if 'patch_embed.weight' in sd:
+        x = sd['patch_embed.weight'][text]                                                         # :407
+    else:                                                                                          # :402-405
+        x = F.linear(sd['patch_embed.0.weight'][text], sd['patch_embed.1.weight'], sd['patch_embed.1.bias'])
+    x = x + sd['pos_embed']                                                                        # :489
+    emb = x
+    x, reps = _student_blocks(x, sd, num_heads, repeated_times, use_transform, cap, need_rep)
+    x = F.linear(_ln(x, sd, 'norm'), sd['head.weight'], sd['head.bias'])                           # :503-504
+    pick = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]                                        # :506
+    return dict(last_representation=pick, last_layer_output=x, representations=reps, embedding=emb)
+
+
+def clip_forward(image_out, text_out):
+    """reference clip_model.py:37-44: L2-normalise (dim=1), logits = img @ txt.T, t2i = logits.T. No logit scale."""
+    i = image_out['last_representation']
+    t = text_out['last_representation']
+    i = i / i.norm(dim=1, keepdim=True)
+    t = t / t.norm(dim=1, keepdim=True)
+    logits = i @ t.t()
+    return dict(visual_output=image_out, text_output=text_out, i2t_logits=logits, t2i_logits=logits.T)

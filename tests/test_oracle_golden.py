@@ -1,0 +1,187 @@
+"""Pin the oracle (oracle/) against goldens produced by the reference's own modules (tools/golden/gen_golden.py).
+
+CPU only.  Tolerances are fp32 re-association noise (the restatement uses einsum for the 1x1 head-mixing conv etc.).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from distillclip_amd import synth
+
+TINY = dict(
+    seed=11, B=3, res=32, patch=8, ctx=13, vocab=97, out_dim=64,
+    s_img=dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4,
+               mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True),
+    s_txt=dict(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2,
+               mlp_ratio=4.0, qkv_bias=False, repeated_times=2, use_transform=True),
+)
+
+
+def T(d, grad=False):
+    out = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+    if grad:
+        for v in out.values():
+            v.requires_grad_(True)
+    return out
+
+
+@pytest.fixture(scope='module')
+def tiny(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, 'tiny.npz')))
+
+
+@pytest.fixture(scope='module')
+def tiny_models():
+    c = TINY
+    return dict(
+        t_img=T(synth.teacher_image_state(c['seed'], 128, 2, c['patch'], c['res'], c['out_dim'])),
+        t_txt=T(synth.teacher_text_state(c['seed'], 128, 2, c['ctx'], c['vocab'], c['out_dim'])),
+        s_img=T(synth.student_image_state(c['seed'], **c['s_img']), grad=True),
+        s_txt=T(synth.student_text_state(c['seed'], **c['s_txt']), grad=True),
+    )
+
+
+def close(a, b, rtol=2e-5, atol=2e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_inputs_regenerate(tiny):
+    c = TINY
+    np.testing.assert_array_equal(synth.images(c['seed'], c['B'], c['res']), tiny['image'])
+    np.testing.assert_array_equal(synth.captions(c['seed'], c['B'], c['ctx'], c['vocab'], 3, 9), tiny['text'])
+
+
+def _forward_all(tiny, m, cap=None, need_rep=False):
+    image, text = torch.from_numpy(tiny['image']), torch.from_numpy(tiny['text'])
+    cap = cap if cap is not None else {}
+    s_img = oracle.student_image_forward(m['s_img'], image, 4, cap=cap.setdefault('s_img', {}), need_rep=need_rep)
+    s_txt = oracle.student_text_forward(m['s_txt'], text, 2, cap=cap.setdefault('s_txt', {}), need_rep=need_rep)
+    with torch.no_grad():
+        t_img = oracle.teacher_image_forward(m['t_img'], image, need_rep=need_rep, need_emb=True)
+        t_txt = oracle.teacher_text_forward(m['t_txt'], text, need_rep=need_rep, need_emb=True)
+    return s_img, s_txt, t_img, t_txt
+
+
+def test_forward_and_intermediates(tiny, tiny_models):
+    cap = {}
+    outs = dict(zip(('s_img', 's_txt', 't_img', 't_txt'), _forward_all(tiny, tiny_models, cap, need_rep=True)))
+    for tag, o in outs.items():
+        close(o['last_representation'], tiny[f'{tag}.last_representation'])
+        close(o['last_layer_output'], tiny[f'{tag}.last_layer_output'])
+        close(o['embedding'], tiny[f'{tag}.embedding'])
+        for i, r in enumerate(o['representations']):
+            close(r, tiny[f'{tag}.rep{i}'])
+    # attention internals of the students: raw scaled scores (pre conv_l) and probs (post softmax, pre conv_w)
+    for tag, nb in (('s_img', 2), ('s_txt', 1)):
+        i = 0
+        for b in range(nb):
+            for r in range(2):
+                close(cap[tag][f'sblock{b}.{r}.scores'], tiny[f'{tag}.scores{i}'])
+                close(cap[tag][f'sblock{b}.{r}.probs'], tiny[f'{tag}.probs{i}'])
+                i += 1
+    so = oracle.clip_forward(outs['s_img'], outs['s_txt'])
+    to = oracle.clip_forward(outs['t_img'], outs['t_txt'])
+    close(so['i2t_logits'], tiny['s.i2t_logits'])
+    close(to['i2t_logits'], tiny['t.i2t_logits'])
+
+
+def _zero_grads(m):
+    for sd in (m['s_img'], m['s_txt']):
+        for v in sd.values():
+            v.grad = None
+
+
+def _check_grads(sd, tiny, prefix, rtol=2e-4):
+    n = 0
+    for k, v in tiny.items():
+        if not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        g = sd[name].grad
+        assert g is not None, name
+        scale = max(float(np.abs(v).max()), 1e-12)
+        np.testing.assert_allclose(g.numpy(), v, rtol=rtol, atol=rtol * scale, err_msg=name)
+        n += 1
+    assert n > 0
+    return n
+
+
+@pytest.mark.parametrize('case', ['all', 'lclip'])
+def test_dual_loss_and_grads(tiny, tiny_models, case):
+    _zero_grads(tiny_models)
+    s_img, s_txt, t_img, t_txt = _forward_all(tiny, tiny_models)
+    if case == 'all':
+        lc = oracle.LossOracle(['out_l1', 'out_cos', 'out_kl', 'cos_diff', 'hard_label', 'soft_label', 'logits_mse'],
+                               {'cos_diff': 0.1, 'soft_label': 0.5}, temperature=2.0)
+    else:
+        lc = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})
+    loss, res = lc(oracle.clip_forward(s_img, s_txt), oracle.clip_forward(t_img, t_txt), 'all')
+    close(loss, tiny[f'{case}.loss'])
+    terms = {k[len(case) + 6:]: v for k, v in tiny.items() if k.startswith(f'{case}.term.')}
+    assert set(terms) == set(res)
+    for k, v in terms.items():
+        close(res[k], v)
+    loss.backward()
+    assert _check_grads(tiny_models['s_img'], tiny, f'{case}.s_img.grad.') >= 30
+    assert _check_grads(tiny_models['s_txt'], tiny, f'{case}.s_txt.grad.') >= 15
+
+
+def test_one_tower_image_with_feature_terms(tiny, tiny_models):
+    _zero_grads(tiny_models)
+    c = TINY
+    image = torch.from_numpy(tiny['image'])
+    so = oracle.student_image_forward(tiny_models['s_img'], image, 4, need_rep=True)
+    with torch.no_grad():
+        to = oracle.teacher_image_forward(tiny_models['t_img'], image, need_layers=[0, 1], need_rep=True, need_emb=True)
+    lc = oracle.LossOracle(['out_l1', 'out_cos', 'hidden_rep_mse', 'embedding_mse'])
+    loss, res = lc(so, to, 'image')
+    close(loss, tiny['img1.loss'])
+    for k in res:
+        close(res[k], tiny['img1.term.' + k])
+    loss.backward()
+    _check_grads(tiny_models['s_img'], tiny, 'img1.s_img.grad.')
+
+
+def test_one_tower_text_and_compressed(tiny, tiny_models):
+    _zero_grads(tiny_models)
+    c = TINY
+    text = torch.from_numpy(tiny['text'])
+    with torch.no_grad():
+        to = oracle.teacher_text_forward(tiny_models['t_txt'], text)
+    lc = oracle.LossOracle(['out_l1', 'out_cos'])
+    so = oracle.student_text_forward(tiny_models['s_txt'], text, 2)
+    loss, res = lc(so, to, 'text')
+    close(loss, tiny['txt1.loss'])
+    loss.backward()
+    _check_grads(tiny_models['s_txt'], tiny, 'txt1.s_txt.grad.')
+    cfg = dict(c['s_txt'], compression_embedding=True, embedding_compression_dim=64)
+    sd = T(synth.student_text_state(c['seed'] + 1, **cfg), grad=True)
+    so = oracle.student_text_forward(sd, text, 2)
+    close(so['last_representation'], tiny['txtc.last_representation'])
+    loss, _ = lc(so, to, 'text')
+    close(loss, tiny['txtc.loss'])
+    loss.backward()
+    _check_grads(sd, tiny, 'txtc.s_txt.grad.')
+
+
+@pytest.mark.parametrize('case', ['b8', 'b37', 'small'])
+def test_loss_components(golden_dir, case):
+    g = dict(np.load(os.path.join(golden_dir, 'loss.npz')))
+    e = {k: torch.from_numpy(g[f'{case}.{k}']) for k in ('si', 'st', 'ti', 'tt')}
+    e['si'].requires_grad_(True)
+    e['st'].requires_grad_(True)
+    mk = lambda i, t: oracle.clip_forward({'last_representation': i}, {'last_representation': t})
+    names = ['out_l1', 'out_cos', 'out_kl', 'cos_diff', 'hard_label', 'soft_label', 'logits_mse', 'out_ce']
+    lc = oracle.LossOracle(names, {'cos_diff': 0.1, 'hard_label': 2.0}, temperature=0.5)
+    loss, res = lc(mk(e['si'], e['st']), mk(e['ti'], e['tt']), 'all')
+    close(loss, g[f'{case}.loss'], rtol=5e-5)
+    for k, v in res.items():
+        close(v, g[f'{case}.term.{k}'], rtol=5e-5, atol=1e-6)
+    loss.backward()
+    for k in ('si', 'st'):
+        ref = g[f'{case}.grad.{k}']
+        np.testing.assert_allclose(e[k].grad.numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())

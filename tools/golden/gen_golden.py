@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+    python tools/golden/gen_golden.py            # needs /root/reference; writes tests/golden/
+
+The reference cannot travel to the GPU box, so only numeric fixtures (seeds, inputs, expected outputs) are
+committed.  Weights/inputs come from distillclip_amd.synth (deterministic, torch-RNG independent) and are
+loaded into the reference modules with load_state_dict.  timm/easydict are absent from the image: the reference's
+weight_share_model.py executes against tools/golden/ref_shims (our restatement of the five timm symbols).
+"""
+import os
+import sys
+import io
+import contextlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF = os.environ.get('DCLIP_REFERENCE', '/root/reference')
+sys.dont_write_bytecode = True
+sys.path[:0] = [REF, os.path.join(HERE, 'ref_shims'), REPO]
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from model.component.image_encoder import ImageEncoder                  # noqa: E402
+    from model.component.text_encoder import TextEncoder                    # noqa: E402
+    from model.component.clip_model import CLIPModel                        # noqa: E402
+    from model.component.output import ControlOutput                        # noqa: E402
+    from model.component.weight_share_model import RepeatVisionTransformer, RepeatTextTransformer  # noqa: E402
+    from model._loss import LossCalculator                                  # noqa: E402
+from distillclip_amd import synth                                           # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def T(d):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_teacher_image(seed, width, layers, patch, res, out_dim, need_layers=None):
+    paras = dict(input_resolution=res, patch_size=patch, width=width, layers=layers, heads=width // 64,
+                 output_dim=out_dim, need_layers=need_layers, drop_out=0.)
+    m = ImageEncoder(is_student=False, vit_paras=paras)
+    m.load_state_dict(T(synth.teacher_image_state(seed, width, layers, patch, res, out_dim)))
+    return m.eval()
+
+
+def build_teacher_text(seed, width, layers, ctx, vocab, out_dim, need_layers=None):
+    m = TextEncoder(transformer_width=width, transformer_layers=layers, transformer_heads=width // 64,
+                    context_length=ctx, need_layers=need_layers, vocab_size=vocab, embed_dim=out_dim,
+                    is_student=False)
+    m.load_state_dict(T(synth.teacher_text_state(seed, width, layers, ctx, vocab, out_dim)))
+    return m.eval()
+
+
+def build_student_image(seed, **cfg):
+    m = quiet(RepeatVisionTransformer, **cfg)
+    m.load_state_dict(T(synth.student_image_state(seed, **cfg)))
+    return m.train()       # reference trains the student in train() mode; all dropouts are p=0
+
+
+def build_student_text(seed, **cfg):
+    m = quiet(RepeatTextTransformer, **cfg)
+    m.load_state_dict(T(synth.student_text_state(seed, **cfg)))
+    return m.train()
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def grads_of(module, prefix=''):
+    return {prefix + 'grad.' + n: np_(p.grad) for n, p in module.named_parameters() if p.grad is not None}
+
+
+TINY = dict(
+    seed=11, B=3, res=32, patch=8, ctx=13, vocab=97, out_dim=64,
+    t_img=dict(width=128, layers=2), t_txt=dict(width=128, layers=2),
+    s_img=dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4,
+               mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True),
+    s_txt=dict(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2,
+               mlp_ratio=4.0, qkv_bias=False, repeated_times=2, use_transform=True),
+)
+ALL_LOSSES = ['out_l1', 'out_cos', 'out_kl', 'cos_diff', 'hard_label', 'soft_label', 'logits_mse']
+
+
+def hook_intermediates(student, store, prefix):
+    """Capture per-(block, repeat) hidden states and attention internals through forward hooks/ControlOutput."""
+    # hidden states and raw scores / probs come out through the reference's own ControlOutput flags.
+    return ControlOutput(need_emb=True, need_attn_score=True, need_attn_prob=True, need_rep=True)
+
+
+def tiny_dual():
+    c = TINY
+    seed, B = c['seed'], c['B']
+    image = torch.from_numpy(synth.images(seed, B, c['res']))
+    text = torch.from_numpy(synth.captions(seed, B, c['ctx'], c['vocab'], 3, 9))
+    t_img = build_teacher_image(seed, c['t_img']['width'], c['t_img']['layers'], c['patch'], c['res'], c['out_dim'])
+    t_txt = build_teacher_text(seed, c['t_txt']['width'], c['t_txt']['layers'], c['ctx'], c['vocab'], c['out_dim'])
+    s_img = build_student_image(seed, **c['s_img'])
+    s_txt = build_student_text(seed, **c['s_txt'])
+    student = CLIPModel(True, s_img, s_txt, False)
+    teacher = CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    out = {'image': np_(image), 'text': np_(text)}
+
+    # pass 1: intermediates through the reference's ControlOutput
+    co = ControlOutput(need_emb=True, need_attn_score=True, need_attn_prob=True, need_rep=True)
+    so = student(text, image, co)
+    to = teacher(text, image, co)
+    for tag, o in (('s_img', so.visual_output), ('s_txt', so.text_output),
+                   ('t_img', to.visual_output), ('t_txt', to.text_output)):
+        out[f'{tag}.last_representation'] = np_(o.last_representation)
+        out[f'{tag}.last_layer_output'] = np_(o.last_layer_output)
+        out[f'{tag}.embedding'] = np_(o.embedding)
+        for i, r in enumerate(o.representations):
+            out[f'{tag}.rep{i}'] = np_(r)
+        for i, r in enumerate(o.attention_scores):
+            out[f'{tag}.scores{i}'] = np_(r)
+        for i, r in enumerate(o.attention_probs):
+            out[f'{tag}.probs{i}'] = np_(r)
+    out['s.i2t_logits'] = np_(so.i2t_logits)
+    out['t.i2t_logits'] = np_(to.i2t_logits)
+
+    # pass 2: training-step semantics (dual_distill_model.py:106-127), every tier-1/2 loss enabled
+    lc = quiet(LossCalculator, loss_name=list(ALL_LOSSES), loss_scale={'cos_diff': 0.1, 'soft_label': 0.5},
+               temperature=2.0)
+    co = lc.get_control_output()
+    so = student(text, image, co)
+    to = teacher(text, image, co)
+    loss, res = lc(so, to, 'all')
+    loss.backward()
+    out['all.loss'] = np_(loss)
+    for k, v in res.items():
+        out['all.term.' + k] = np_(v)
+    out.update(grads_of(s_img, 'all.s_img.'))
+    out.update(grads_of(s_txt, 'all.s_txt.'))
+    student.zero_grad()
+
+    # pass 3: the l_clip.yaml loss set (l_clip.yaml:29-32)
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})
+    so = student(text, image, lc.get_control_output())
+    to = teacher(text, image, lc.get_control_output())
+    loss, res = lc(so, to, 'all')
+    loss.backward()
+    out['lclip.loss'] = np_(loss)
+    for k, v in res.items():
+        out['lclip.term.' + k] = np_(v)
+    out.update(grads_of(s_img, 'lclip.s_img.'))
+    out.update(grads_of(s_txt, 'lclip.s_txt.'))
+    student.zero_grad()
+
+    # pass 4: one-tower runs (distil_model.py:81-102) with the image.yaml / text.yaml loss set + feature terms
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos', 'hidden_rep_mse', 'embedding_mse'])
+    co = lc.get_control_output()
+    t4 = build_teacher_image(seed, c['t_img']['width'], c['t_img']['layers'], c['patch'], c['res'], c['out_dim'],
+                             need_layers=[0, 1])
+    so = s_img(image, co)
+    with torch.no_grad():
+        to = t4(image, co)
+    # the student emits 4 reps (depth 4) and the teacher 2: the reference zips them (hidden_mse.py:11) -> first 2
+    loss, res = lc(so, to, 'image')
+    loss.backward()
+    out['img1.loss'] = np_(loss)
+    for k, v in res.items():
+        out['img1.term.' + k] = np_(v)
+    out.update(grads_of(s_img, 'img1.s_img.'))
+    s_img.zero_grad()
+
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos'])
+    so = s_txt(text, lc.get_control_output())
+    with torch.no_grad():
+        to = t_txt(text, lc.get_control_output())
+    loss, res = lc(so, to, 'text')
+    loss.backward()
+    out['txt1.loss'] = np_(loss)
+    for k, v in res.items():
+        out['txt1.term.' + k] = np_(v)
+    out.update(grads_of(s_txt, 'txt1.s_txt.'))
+    s_txt.zero_grad()
+
+    # compressed-embedding text student (text.yaml:10)
+    cfg = dict(c['s_txt'], compression_embedding=True, embedding_compression_dim=64)
+    s_txt_c = build_student_text(seed + 1, **cfg)
+    so = s_txt_c(text, lc.get_control_output())
+    loss, res = lc(so, to, 'text')
+    loss.backward()
+    out['txtc.loss'] = np_(loss)
+    out['txtc.last_representation'] = np_(so.last_representation)
+    out.update(grads_of(s_txt_c, 'txtc.s_txt.'))
+    np.savez_compressed(os.path.join(OUT, 'tiny.npz'), **out)
+    print('tiny.npz', len(out), 'arrays')
+
+
+def loss_only():
+    """LossCalculator + loss_component goldens on random embeddings (incl. eps / edge behaviour)."""
+    from types import SimpleNamespace as NS
+    out = {}
+    for case, (B, D, scale) in {'b8': (8, 64, 1.0), 'b37': (37, 512, 1.0), 'small': (5, 32, 1e-7)}.items():
+        e = {k: torch.from_numpy(synth.normal(5, f'{case}.{k}', (B, D), scale)) for k in ('si', 'st', 'ti', 'tt')}
+        e['si'].requires_grad_(True)
+        e['st'].requires_grad_(True)
+
+        def clip_out(i, t):
+            fi = i / i.norm(dim=1, keepdim=True)
+            ft = t / t.norm(dim=1, keepdim=True)
+            lg = fi @ ft.t()
+            return NS(visual_output=NS(last_representation=i), text_output=NS(last_representation=t),
+                      i2t_logits=lg, t2i_logits=lg.T)
+        names = list(ALL_LOSSES) + ['out_ce']
+        lc = quiet(LossCalculator, loss_name=names, loss_scale={'cos_diff': 0.1, 'hard_label': 2.0},
+                   temperature=0.5)
+        loss, res = lc(clip_out(e['si'], e['st']), clip_out(e['ti'], e['tt']), 'all')
+        loss.backward()
+        for k, v in e.items():
+            out[f'{case}.{k}'] = np_(v)
+        out[f'{case}.loss'] = np_(loss)
+        for k, v in res.items():
+            out[f'{case}.term.{k}'] = np_(v)
+        out[f'{case}.grad.si'] = np_(e['si'].grad)
+        out[f'{case}.grad.st'] = np_(e['st'].grad)
+    np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
+    print('loss.npz', len(out), 'arrays')
+
+
+def real_shapes():
+    """ViT-B/32 teacher + the shipped l_clip students, B=4: outputs only (SURVEY.md §8c family 2)."""
+    seed, B = 2022, 4
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    text = torch.from_numpy(synth.captions(seed, B))
+    t_img = build_teacher_image(seed, 768, 12, 32, 224, 512)
+    t_txt = build_teacher_text(seed, 512, 12, 77, 49408, 512)
+    s_img_cfg = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                     mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    s_img = build_student_image(seed, **s_img_cfg)
+    s_txt = build_student_text(seed, **s_txt_cfg)
+    student = CLIPModel(True, s_img, s_txt, False)
+    teacher = CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})
+    so = student(text, image, lc.get_control_output())
+    with torch.no_grad():
+        to = teacher(text, image, lc.get_control_output())
+    loss, res = lc(so, to, 'all')
+    loss.backward()
+    out = {'seed': np.int64(seed), 'B': np.int64(B), 'loss': np_(loss)}
+    for k, v in res.items():
+        out['term.' + k] = np_(v)
+    out['s_img.last_representation'] = np_(so.visual_output.last_representation)
+    out['s_txt.last_representation'] = np_(so.text_output.last_representation)
+    out['t_img.last_representation'] = np_(to.visual_output.last_representation)
+    out['t_txt.last_representation'] = np_(to.text_output.last_representation)
+    out['s.i2t_logits'] = np_(so.i2t_logits)
+    out['t.i2t_logits'] = np_(to.i2t_logits)
+    # gradient fingerprints: L2 norm per parameter + a small slice of a few
+    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+        for n, p in m.named_parameters():
+            g = p.grad
+            out[f'{tag}.gnorm.{n}'] = np_(g.norm())
+        for n in ('head.weight', 'blocks.0.block.attn.qkv.weight', 'blocks.0.block.attn.conv_l.instances.1.weight',
+                  'blocks.1.block.mlp.fc2.weight', 'pos_embed'):
+            g = dict(m.named_parameters())[n].grad
+            out[f'{tag}.gslice.{n}'] = np_(g.reshape(-1)[:256])
+    np.savez_compressed(os.path.join(OUT, 'real_b4.npz'), **out)
+    print('real_b4.npz', len(out), 'arrays', 'loss', float(loss))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['tiny', 'loss', 'real']
+    if 'tiny' in which:
+        tiny_dual()
+    if 'loss' in which:
+        loss_only()
+    if 'real' in which:
+        real_shapes()
