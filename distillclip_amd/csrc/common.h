@@ -1,0 +1,63 @@
+// Common device/host helpers for the distill-step kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#include "dclip.h"   // DCLIP_OK / DCLIP_EINVAL (bad shape, dtype, alignment -> ValueError in Python) / DCLIP_ELAUNCH (-> RuntimeError)
+
+// thread-local last-error string (include/dclip.h: dclip_last_error_string)
+void dclip_set_error(const char* fmt, ...);
+
+#define DCLIP_REQUIRE(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            dclip_set_error(__VA_ARGS__);         \
+            return DCLIP_EINVAL;                  \
+        }                                         \
+    } while (0)
+
+static inline int dclip_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dclip_set_error("%s: %s", what, hipGetErrorString(e));
+        return DCLIP_ELAUNCH;
+    }
+    return DCLIP_OK;
+}
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf_f(float x) {
+    // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.3989422804014327f;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: blocks that share an XCD (same id % 8 under the
+// observed round-robin placement) get a contiguous chunk of the tile space, so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}

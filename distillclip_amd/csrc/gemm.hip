@@ -1,0 +1,355 @@
+// bf16 MFMA GEMMs for the distill step (gfx950).
+//
+//   gemm_nt      C[M,N] = epi(alpha * A[M,K] · B[N,K]^T)      forward linears, dgrad (with pre-transposed W)
+//   gemm_tn_acc  dW[P,Q] += A[M,P]^T · B[M,Q]                 wgrad (contraction over tokens), f32 atomics
+//   colsum_acc   db[N]   += sum_m X[m,N]                      bias grad
+//
+// gemm_nt: 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of v_mfma_f32_16x16x32_bf16.
+// Operands go HBM -> LDS with global_load_lds (16 B/lane, no VGPR staging), double buffered, one barrier per
+// K-tile.  The LDS image is made of 1 KiB [16 rows x 32 k] sub-tiles (one per wave-instruction) with the
+// st_16x32 XOR swizzle (byte ^= ((byte >> 9) & 1) << 5) applied on the SOURCE address and again on the
+// ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int SUB = 1024;                       // bytes of one [16 x 32] bf16 sub-tile
+constexpr int TILE_BYTES = (BM / 16) * (BK / 32) * SUB;   // 16 KiB per operand per stage
+
+struct GemmNT {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int M, N, K;
+    float alpha;
+    const float* bias;
+    const bf16_t* aux_in;
+    bf16_t* aux_out;
+    const float* residual; int64_t ldr;
+    int row_group; const float* rowadd;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+// one wave stages 4 of the 16 sub-tiles of an operand tile
+__device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max,
+                                              int k0, char* lds_tile, int wave, int lane) {
+    const int L = lane * 16;
+    const int X = swz(L);
+    const int r = X >> 6, c = (X >> 4) & 3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int sub = wave * 4 + s;          // sub = rb * 2 + kb
+        const int rb = sub >> 1, kb = sub & 1;
+        int row = row0 + rb * 16 + r;
+        row = row < rows_max ? row : rows_max - 1;
+        const bf16_t* src = G + (int64_t)row * ld + (k0 + kb * 32 + c * 8);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + sub * SUB), 16, 0, 0);
+    }
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;     // n fastest: the A row-panel stays in this XCD's L2
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    char* As = smem;
+    char* Bs = smem + 2 * TILE_BYTES;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage_operand(p.A, p.lda, m0, p.M, 0, As, wave, lane);
+    stage_operand(p.B, p.ldb, n0, p.N, 0, Bs, wave, lane);
+
+    const int fragoff = swz((lane & 15) * 64 + (lane >> 4) * 16);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();   // tile kt landed (the fence drains vmcnt) and every wave left buffer (kt+1)&1
+        if (kt + 1 < nk) {
+            const int nb = (kt + 1) & 1;
+            stage_operand(p.A, p.lda, m0, p.M, (kt + 1) * BK, As + nb * TILE_BYTES, wave, lane);
+            stage_operand(p.B, p.ldb, n0, p.N, (kt + 1) * BK, Bs + nb * TILE_BYTES, wave, lane);
+        }
+        const char* a_t = As + (kt & 1) * TILE_BYTES;
+        const char* b_t = Bs + (kt & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *(const bf16x8*)(a_t + ((wm * 4 + i) * 2 + kb) * SUB + fragoff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[j] = *(const bf16x8*)(b_t + ((wn * 4 + j) * 2 + kb) * SUB + fragoff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: acc[i][j][r] is C[row = i*16 + (lane>>4)*4 + r][col = j*16 + (lane&15)] of the wave's 64x64 tile
+    const int colb = n0 + wn * 64 + (lane & 15);
+    const int rowb = m0 + wm * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = colb + j * 16;
+        if (col >= p.N) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + i * 16 + r;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha + bias;
+                int64_t orow = row;
+                if (p.row_group > 0) {
+                    const int g = row / p.row_group, w = row - g * p.row_group;
+                    orow = row + g + 1;
+                    v += p.rowadd[(int64_t)(w + 1) * p.N + col];
+                }
+                const int64_t o = orow * p.ldc + col;
+                if (p.aux_out) p.aux_out[o] = f2bf(v);
+                if (ACT == 1) v = quick_gelu_f(v);
+                if (ACT == 2) v = gelu_erf_f(v);
+                if (ACT == 3) v *= dgelu_erf_f(bf2f(p.aux_in[o]));
+                if (p.residual) v += p.residual[orow * p.ldr + col];
+                if (OUT_F32) ((float*)p.C)[o] = v;
+                else ((bf16_t*)p.C)[o] = f2bf(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad: out[P,Q] += sum_m A[m,P] * B[m,Q].  Both operands are "k-major" (the contraction index m is the row),
+// so MFMA fragments (8 consecutive k per lane) need a transpose: tiles are staged row-major into LDS through
+// registers (rows padded to 288 B) and read back with ds_read_b64_tr_b16 (guide T10).
+// ------------------------------------------------------------------------------------------------------
+constexpr int TP = 128, TQ = 128, TC = 64;          // output tile and contraction chunk
+constexpr int TROW = 288;                           // padded LDS row stride in bytes (128 bf16 + 32 B)
+constexpr int TTILE = TC * TROW;                    // 18 KiB
+
+struct GemmTN {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* B; int64_t ldb;
+    float* out; int64_t ldo;
+    int M, P, Q;
+    int tiles_p, tiles_q, splits, chunk;            // chunk = rows of M per split (multiple of TC)
+};
+
+// load a [64 x 128] bf16 tile (rows m0.., cols c0..) into registers: 4 x 16 B per thread
+__device__ __forceinline__ void tn_load(const bf16_t* __restrict__ G, int64_t ld, int m0, int m_end, int c0, int cols,
+                                        int tid, u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = s * 256 + tid;          // 0..1023 chunks of 16 B; 16 chunks per row
+        const int r = idx >> 4, c = (idx & 15) * 8;
+        const int row = m0 + r, col = c0 + c;
+        if (row < m_end && col < cols) regs[s] = *(const u32x4*)(G + (int64_t)row * ld + col);
+        else regs[s] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+__device__ __forceinline__ void tn_store(char* tile, int tid, const u32x4 (&regs)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = s * 256 + tid;
+        const int r = idx >> 4, c = (idx & 15);
+        *(u32x4*)(tile + r * TROW + c * 16) = regs[s];
+    }
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// fragment of a k-major tile: 16 columns starting at x0, 32 rows starting at r0 (lane: col x0+(l&15), k = 8(l>>4)+e)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int x0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const char* a0 = tile + (r0 + 8 * g + q) * TROW + (x0 + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * TROW));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+
+    int t = blockIdx.x;
+    const int split = t % p.splits; t /= p.splits;
+    const int tq = t % p.tiles_q, tp = t / p.tiles_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int m_begin = split * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    if (m_begin >= m_end) return;
+
+    char* As = smem;                 // [2][TTILE]
+    char* Bs = smem + 2 * TTILE;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    const int nc = (m_end - m_begin + TC - 1) / TC;
+    tn_load(p.A, p.lda, m_begin, m_end, p0, p.P, tid, ra);
+    tn_load(p.B, p.ldb, m_begin, m_end, q0, p.Q, tid, rb);
+    tn_store(As, tid, ra);
+    tn_store(Bs, tid, rb);
+
+    for (int ct = 0; ct < nc; ++ct) {
+        __syncthreads();
+        const bool more = ct + 1 < nc;
+        if (more) {
+            tn_load(p.A, p.lda, m_begin + (ct + 1) * TC, m_end, p0, p.P, tid, ra);
+            tn_load(p.B, p.ldb, m_begin + (ct + 1) * TC, m_end, q0, p.Q, tid, rb);
+        }
+        const char* a_t = As + (ct & 1) * TTILE;
+        const char* b_t = Bs + (ct & 1) * TTILE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tr_frag(a_t, kb * 32, wp * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(b_t, kb * 32, wq * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            // buffer (ct+1)&1 was last read in iteration ct-1; every wave passed this iteration's barrier since
+            tn_store(As + ((ct + 1) & 1) * TTILE, tid, ra);
+            tn_store(Bs + ((ct + 1) & 1) * TTILE, tid, rb);
+        }
+    }
+
+    const int colb = q0 + wq * 64 + (lane & 15);
+    const int rowb = p0 + wp * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rowb + i * 16 + r;
+            if (row >= p.P) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = colb + j * 16;
+                if (col < p.Q) unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, acc[i][j][r]);
+            }
+        }
+}
+
+// column sums: grid (ceil(N/256) , row_splits); each thread owns one column, strides rows
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int64_t ld, float* __restrict__ db,
+                                                     int M, int N, int rows_per_block) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += bf2f(X[(int64_t)r * ld + col]);
+        s1 += bf2f(X[(int64_t)(r + 1) * ld + col]);
+        s2 += bf2f(X[(int64_t)(r + 2) * ld + col]);
+        s3 += bf2f(X[(int64_t)(r + 3) * ld + col]);
+    }
+    for (; r < r1; ++r) s0 += bf2f(X[(int64_t)r * ld + col]);
+    unsafeAtomicAdd(db + col, (s0 + s1) + (s2 + s3));
+}
+
+template <int ACT>
+int launch_nt(const GemmNT& p, bool out_f32, hipStream_t st) {
+    const int grid = p.tiles_m * p.tiles_n;
+    const size_t lds = 4 * TILE_BYTES;
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<ACT, false>), dim3(grid), dim3(256), lds, st, p);
+    return dclip_check_launch("dclip_gemm_nt");
+}
+
+}  // namespace
+
+extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                             int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
+                             const void* aux_in, void* aux_out, const float* residual, int64_t ldr, int out_f32,
+                             int64_t row_group, const float* rowadd, void* stream) {
+    DCLIP_REQUIRE(A && B && C, "dclip_gemm_nt: null operand");
+    DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "dclip_gemm_nt: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    DCLIP_REQUIRE(K % BK == 0, "dclip_gemm_nt: K=%ld must be a multiple of %d", (long)K, BK);
+    DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                  "dclip_gemm_nt: operand rows must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
+    DCLIP_REQUIRE(act >= 0 && act <= 3, "dclip_gemm_nt: bad activation code %d", act);
+    DCLIP_REQUIRE(act != DCLIP_ACT_DGELU || aux_in, "dclip_gemm_nt: DGELU needs aux_in");
+    DCLIP_REQUIRE(row_group == 0 || rowadd, "dclip_gemm_nt: row_group needs rowadd");
+    DCLIP_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "dclip_gemm_nt: dimension overflow");
+    GemmNT p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha; p.bias = bias;
+    p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.residual = residual; p.ldr = ldr;
+    p.row_group = (int)row_group; p.rowadd = rowadd;
+    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+    hipStream_t st = (hipStream_t)stream;
+    switch (act) {
+        case 0: return launch_nt<0>(p, out_f32 != 0, st);
+        case 1: return launch_nt<1>(p, out_f32 != 0, st);
+        case 2: return launch_nt<2>(p, out_f32 != 0, st);
+        default: return launch_nt<3>(p, out_f32 != 0, st);
+    }
+}
+
+extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t ldo,
+                                 int64_t M, int64_t P, int64_t Q, int splits, void* stream) {
+    DCLIP_REQUIRE(A && B && dW, "dclip_gemm_tn_acc: null operand");
+    DCLIP_REQUIRE(M > 0 && P > 0 && Q > 0, "dclip_gemm_tn_acc: empty problem");
+    DCLIP_REQUIRE(P % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                  ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                  "dclip_gemm_tn_acc: P, Q, lda, ldb must be multiples of 8 and bases 16-byte aligned");
+    DCLIP_REQUIRE(splits >= 1, "dclip_gemm_tn_acc: splits must be >= 1");
+    GemmTN p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.out = dW; p.ldo = ldo;
+    p.M = (int)M; p.P = (int)P; p.Q = (int)Q;
+    p.tiles_p = (int)((P + TP - 1) / TP); p.tiles_q = (int)((Q + TQ - 1) / TQ);
+    int chunk = (int)((M + splits - 1) / splits);
+    chunk = ((chunk + TC - 1) / TC) * TC;
+    p.chunk = chunk;
+    p.splits = (int)((M + chunk - 1) / chunk);
+    const int grid = p.tiles_p * p.tiles_q * p.splits;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
+    return dclip_check_launch("dclip_gemm_tn_acc");
+}
+
+extern "C" int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N, void* stream) {
+    DCLIP_REQUIRE(X && db && M > 0 && N > 0, "dclip_colsum_acc: bad argument");
+    int rows_per_block = 512;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ld, db, (int)M, (int)N,
+                       rows_per_block);
+    return dclip_check_launch("dclip_colsum_acc");
+}
