@@ -11,6 +11,7 @@ _LIB_PATH = os.path.join(_HERE, 'libdistillclip_hip.so')
 _HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'dclip.h')
 
 _CT = {
+    "int32_t": ctypes.c_int32,
     'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
     'double': ctypes.c_double,
 }
@@ -24,7 +25,7 @@ def _parse_header(path=_HEADER):
     src = re.sub(r'^\s*#[^\n]*$', '', src, flags=re.M)
     src = src.replace('extern "C" {', '')
     protos = {}
-    for m in re.finditer(r'((?:const\s+)?(?:int|void|char|float|size_t|int64_t)[\s\*]*?)\b(dclip_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'((?:const\s+)?(?:int|void|char|float|size_t|int64_t|int32_t)[\s\*]*?)\b(dclip_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
         protos[name] = (_ctype(ret), [] if args in ('', 'void') else [_ctype(a) for a in args.split(',')])
     return protos

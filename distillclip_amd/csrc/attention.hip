@@ -1,0 +1,528 @@
+// Attention kernels (gfx950): per-(batch, head) bf16 MFMA products + the head-mixing softmax stage.
+//
+//   reference teacher: model/component/_common.py:73-89   (QK^T / sqrt(hd), + causal mask, softmax, PV)
+//   reference student: model/component/weight_share_model.py:101-125
+//                      (q *= scale ; QK^T ; conv_l over heads ; softmax ; conv_w over heads ; PV)
+//
+// The sequences are tiny (N = 50 / 77 / 101) so one wave owns one (b, h) problem and the whole row of scores.
+// Three MFMA product shapes cover forward and backward (all v_mfma_f32_16x16x32_bf16, f32 accumulate):
+//   NT  C[i,j] = a * sum_d A[i,d] B[j,d]     scores S = QK^T ; dR = dO V^T        (fragments straight from HBM/L2)
+//   NN  C[i,d] = a * sum_j A[i,j] B[j,d]     O = R V ; dQ = dS K                  (B through LDS + tr16 reads)
+//   TN  C[j,d] = a * sum_i A[i,j] B[i,d]     dV = R^T dO ; dK = dS^T Q            (A and B through LDS + tr16 reads)
+// The softmax / head-mix stage is fp32 VALU with one wave per (b, query row); its weight gradients
+// (dW_l, dW_w: H x H, reduced over B*N*N positions) run on 32x32x16 MFMA from LDS tiles.
+//
+// Score-like tensors live as [B, H, N, Np] with Np = round_up(N, 8) (16-byte rows); pad columns are zero.
+// q/k/v/ctx are token-major: row = b*N + n, column = head*hd + d (+ which*D inside the fused qkv buffer).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct AttnMM {
+    const void* A; int64_t lda;      // NT: token-major bf16 ; NN/TN: [B,H,N,Np] bf16 (lda = Np)
+    const bf16_t* Bm; int64_t ldb;   // token-major bf16
+    void* C; int64_t ldc;            // NT: [B,H,N,Np] (f32 or bf16, ldc = Np) ; NN/TN: token-major bf16
+    int B, H, N, Np, hd;
+    float alpha;
+};
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NT: one wave per (b,h).  HD = head dim (32 or 64).
+// ---------------------------------------------------------------------------------------------------------
+template <int HD, bool OUT_F32>
+__global__ __launch_bounds__(256) void attn_nt_kernel(AttnMM p) {
+    const int lane = threadIdx.x & 63;
+    const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prob >= p.B * p.H) return;
+    const int b = prob / p.H, h = prob % p.H;
+    const bf16_t* A = (const bf16_t*)p.A + (int64_t)b * p.N * p.lda + h * HD;
+    const bf16_t* Bm = p.Bm + (int64_t)b * p.N * p.ldb + h * HD;
+    const int nt = (p.N + 15) >> 4;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    constexpr int KS = HD / 32;
+    for (int it = 0; it < nt; ++it) {
+        const int ia = min(it * 16 + fr, p.N - 1);
+        bf16x8 af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
+        for (int jt = 0; jt < nt; ++jt) {
+            const int jb = min(jt * 16 + fr, p.N - 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 bf = *(const bf16x8*)(Bm + (int64_t)jb * p.ldb + ks * 32 + fk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc, 0, 0, 0);
+            }
+            const int j = jt * 16 + fr;
+            if (j < p.Np) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + (lane >> 4) * 4 + r;
+                    if (i < p.N) {
+                        const float v = j < p.N ? acc[r] * p.alpha : 0.f;
+                        const int64_t o = (((int64_t)b * p.H + h) * p.N + i) * p.ldc + j;
+                        if (OUT_F32) ((float*)p.C)[o] = v;
+                        else ((bf16_t*)p.C)[o] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// k-major LDS tile fragment (16 columns from x0, 32 rows from r0): two ds_read_b64_tr_b16
+template <int ROWB>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int x0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const char* a0 = tile + (r0 + 8 * g + q) * ROWB + (x0 + 4 * pp) * 2;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
+    return u.v;
+}
+
+// copy `rows` x `cols` bf16 (cols % 8 == 0) from global (row stride ld) into a wave-private LDS tile (row stride ROWB
+// bytes), zero-filling rows >= rows_valid ; rows is a multiple of 32
+template <int ROWB>
+__device__ __forceinline__ void wave_stage(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_valid, int rows,
+                                           int cols, char* tile, int lane) {
+    const int cpr = cols >> 3;                 // 16-byte chunks per row
+    const int total = rows * cpr;
+    for (int idx = lane; idx < total; idx += 64) {
+        const int r = idx / cpr, c = idx - r * cpr;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < rows_valid) v = *(const u32x4*)(G + (int64_t)(row0 + r) * ld + c * 8);
+        *(u32x4*)(tile + r * ROWB + c * 16) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NN: C[(b,i), h*HD + d] = alpha * sum_j A[b,h,i,j] * B[(b,j), h*HD + d]
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NMAX = 128;                      // max padded sequence length handled by the attention kernels
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
+    constexpr int ROWB = HD * 2 + 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nprob = p.B * p.H;
+    const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
+    const bool live = blockIdx.x * 4 + wave < nprob;
+    const int b = prob / p.H, h = prob % p.H;
+    const int n32 = (p.N + 31) & ~31;
+    char* tile = smem + wave * (NMAX * ROWB);
+    wave_stage<ROWB>(p.Bm + (int64_t)b * p.N * p.ldb + h * HD, p.ldb, 0, p.N, n32, HD, tile, lane);
+    __syncthreads();
+    const bf16_t* A = (const bf16_t*)p.A + ((int64_t)b * p.H + h) * p.N * p.lda;
+    const int nt = (p.N + 15) >> 4, nks = n32 >> 5;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    constexpr int DT = HD / 16;
+    for (int it = 0; it < nt; ++it) {
+        const int ia = min(it * 16 + fr, p.N - 1);
+        f32x4 acc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nks; ++ks) {
+            const int j0 = ks * 32 + fk;
+            const bf16x8 af = j0 < p.Np ? *(const bf16x8*)(A + (int64_t)ia * p.lda + j0) : zero_frag();
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const bf16x8 bf = tr_frag<ROWB>(tile, ks * 32, d * 16, lane);
+                acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[d], 0, 0, 0);
+            }
+        }
+        if (live) {
+            bf16_t* C = (bf16_t*)p.C + (int64_t)b * p.N * p.ldc + h * HD;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + (lane >> 4) * 4 + r;
+                    if (i < p.N) C[(int64_t)i * p.ldc + d * 16 + fr] = f2bf(acc[d][r] * p.alpha);
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// TN: C[(b,j), h*HD + d] = alpha * sum_i A[b,h,i,j] * B[(b,i), h*HD + d]   (contraction over query rows)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TN_MAXJ = NMAX / 16;             // 8 output row tiles
+constexpr int TN_AROW = NMAX * 2 + 32;         // 288 B rows for the A chunk [32 x Np]
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
+    constexpr int BROW = HD * 2 + 32;
+    constexpr int DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nprob = p.B * p.H;
+    const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
+    const bool live = blockIdx.x * 4 + wave < nprob;
+    const int b = prob / p.H, h = prob % p.H;
+    char* at = smem + wave * (32 * TN_AROW + 32 * BROW);
+    char* bt = at + 32 * TN_AROW;
+    const bf16_t* A = (const bf16_t*)p.A + ((int64_t)b * p.H + h) * p.N * p.lda;
+    const bf16_t* Bm = p.Bm + (int64_t)b * p.N * p.ldb + h * HD;
+    const int ntj = (p.N + 15) >> 4;
+    const int nchunk = (p.N + 31) >> 5;
+    f32x4 acc[TN_MAXJ][DT];
+#pragma unroll
+    for (int j = 0; j < TN_MAXJ; ++j)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        wave_stage<TN_AROW>(A, p.lda, ch * 32, p.N, 32, p.Np, at, lane);
+        wave_stage<BROW>(Bm, p.ldb, ch * 32, p.N, 32, HD, bt, lane);
+        __syncthreads();
+        bf16x8 bf[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) bf[d] = tr_frag<BROW>(bt, 0, d * 16, lane);
+#pragma unroll
+        for (int j = 0; j < TN_MAXJ; ++j) {
+            if (j < ntj) {
+                // columns beyond Np were never staged: they only feed output rows >= N, which are not stored
+                const bf16x8 af = tr_frag<TN_AROW>(at, 0, j * 16, lane);
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+                    acc[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[d], acc[j][d], 0, 0, 0);
+            }
+        }
+    }
+    if (live) {
+        bf16_t* C = (bf16_t*)p.C + (int64_t)b * p.N * p.ldc + h * HD;
+#pragma unroll
+        for (int j = 0; j < TN_MAXJ; ++j)
+            if (j < ntj)
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jj = j * 16 + (lane >> 4) * 4 + r;
+                        if (jj < p.N) C[(int64_t)jj * p.ldc + d * 16 + (lane & 15)] = f2bf(acc[j][d][r] * p.alpha);
+                    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// softmax with optional cross-head mixes, one wave per (b, query row i); lane <-> key j (+64 per slot)
+//   A_g = sum_h Wl[g,h] S_h ; P_g = softmax_j(A_g) (causal: j <= i) ; R_g = sum_h Ww[g,h] P_h
+// ---------------------------------------------------------------------------------------------------------
+struct SoftmaxFwd {
+    const float* S;          // [B,H,N,Np] f32
+    const float* Wl;         // [H,H] or null
+    const float* Ww;         // [H,H] or null
+    bf16_t* P;               // [B,H,N,Np] or null (saved for backward when Ww is set)
+    bf16_t* R;               // [B,H,N,Np]
+    int B, N, Np, causal;
+};
+
+template <int H, int NS>
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(SoftmaxFwd p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B * p.N) return;
+    const int b = row / p.N, i = row % p.N;
+    const int64_t hs = (int64_t)p.N * p.Np;                       // head stride
+    const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
+    float sv[NS][H];
+    bool valid[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = lane + 64 * s;
+        valid[s] = j < p.N && (!p.causal || j <= i);
+#pragma unroll
+        for (int h = 0; h < H; ++h) sv[s][h] = j < p.N ? p.S[base + h * hs + j] : 0.f;
+    }
+    float pr[NS][H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+        float a[NS];
+        float m = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (p.Wl) {
+                float t = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) t = fmaf(p.Wl[g * H + h], sv[s][h], t);
+                a[s] = t;
+            } else {
+                a[s] = sv[s][g];
+            }
+            if (!valid[s]) a[s] = -INFINITY;
+            m = fmaxf(m, a[s]);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            a[s] = valid[s] ? __expf(a[s] - m) : 0.f;
+            sum += a[s];
+        }
+        const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pr[s][g] = a[s] * inv;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = lane + 64 * s;
+        if (j < p.Np) {
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                if (p.P) p.P[base + g * hs + j] = f2bf(pr[s][g]);
+                float r = pr[s][g];
+                if (p.Ww) {
+                    r = 0.f;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) r = fmaf(p.Ww[g * H + h], pr[s][h], r);
+                }
+                p.R[base + g * hs + j] = f2bf(r);
+            }
+        }
+    }
+}
+
+// backward of the stage above.  dP = Ww^T dR ; dA = P o (dP - sum_j P dP) ; dS = Wl^T dA
+// dWw[g,h] += sum dR_g P_h ; dWl[g,h] += sum dA_g S_h     (32x32x16 MFMA over the key axis, per-wave accumulators)
+struct SoftmaxBwd {
+    const bf16_t* dR;        // [B,H,N,Np]
+    const bf16_t* P;         // [B,H,N,Np] (post-softmax, pre conv_w)
+    const float* S;          // [B,H,N,Np] raw scores (only read when Wl is set)
+    const float* Wl;
+    const float* Ww;
+    bf16_t* dS;              // [B,H,N,Np]
+    float* dWl;              // [H,H] += (may be null)
+    float* dWw;
+    int B, N, Np;
+};
+
+template <int H, int NS>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(SoftmaxBwd p) {
+    constexpr int COLS = 64 * NS;               // keys per LDS row
+    constexpr int ROWB = COLS * 2 + 16;         // bytes per LDS row (+16: spreads the 32 rows over banks)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* xa = smem + wave * (2 * 32 * ROWB);   // [32][COLS] "g" operand
+    char* xb = xa + 32 * ROWB;                  // [32][COLS] "h" operand
+    const bool mix = p.Wl != nullptr;           // student path (both mixes) ; teacher never runs backward
+    if (mix) {
+        // rows H..31 stay zero for the whole kernel
+        for (int idx = lane; idx < 2 * 32 * ROWB / 4; idx += 64) ((unsigned*)xa)[idx] = 0u;
+    }
+    f32x16 accw = {0}, accl = {0};
+    const int64_t hs = (int64_t)p.N * p.Np;
+    const int rows = p.B * p.N;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int b = row / p.N, i = row % p.N;
+        const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
+        float dr[NS][H], pv[NS][H];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int j = lane + 64 * s;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                dr[s][h] = j < p.N ? bf2f(p.dR[base + h * hs + j]) : 0.f;
+                pv[s][h] = j < p.N ? bf2f(p.P[base + h * hs + j]) : 0.f;
+            }
+        }
+        if (mix) {
+            // dWw += dR_g P_h : stage both as bf16 rows [g][j] / [h][j]
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    *(bf16_t*)(xa + h * ROWB + (lane + 64 * s) * 2) = f2bf(dr[s][h]);
+                    *(bf16_t*)(xb + h * ROWB + (lane + 64 * s) * 2) = f2bf(pv[s][h]);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < COLS / 16; ++ks) {
+                const bf16x8 af = *(const bf16x8*)(xa + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
+                const bf16x8 bf = *(const bf16x8*)(xb + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
+                accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accw, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // dP = Ww^T dR
+        float da[NS][H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float t[NS];
+            float rs = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float dp;
+                if (p.Ww) {
+                    dp = 0.f;
+#pragma unroll
+                    for (int g = 0; g < H; ++g) dp = fmaf(p.Ww[g * H + h], dr[s][g], dp);
+                } else {
+                    dp = dr[s][h];
+                }
+                t[s] = dp;
+                rs += dp * pv[s][h];
+            }
+            rs = wave_sum(rs);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) da[s][h] = pv[s][h] * (t[s] - rs);
+        }
+        if (mix) {
+            float sv[NS][H];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int j = lane + 64 * s;
+#pragma unroll
+                for (int h = 0; h < H; ++h) sv[s][h] = j < p.N ? p.S[base + h * hs + j] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    *(bf16_t*)(xa + h * ROWB + (lane + 64 * s) * 2) = f2bf(da[s][h]);
+                    *(bf16_t*)(xb + h * ROWB + (lane + 64 * s) * 2) = f2bf(sv[s][h]);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < COLS / 16; ++ks) {
+                const bf16x8 af = *(const bf16x8*)(xa + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
+                const bf16x8 bf = *(const bf16x8*)(xb + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accl, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // dS = Wl^T dA
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int j = lane + 64 * s;
+            if (j < p.Np) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float ds;
+                    if (p.Wl) {
+                        ds = 0.f;
+#pragma unroll
+                        for (int g = 0; g < H; ++g) ds = fmaf(p.Wl[g * H + h], da[s][g], ds);
+                    } else {
+                        ds = da[s][h];
+                    }
+                    p.dS[base + h * hs + j] = f2bf(j < p.N ? ds : 0.f);
+                }
+            }
+        }
+    }
+    if (mix) {
+        // acc[reg] is element (g = (reg&3) + 8*(reg>>2) + 4*(lane>>5), h = lane&31)
+        const int hcol = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int g = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (g < H && hcol < H) {
+                if (p.dWw) unsafeAtomicAdd(p.dWw + g * H + hcol, accw[r]);
+                if (p.dWl) unsafeAtomicAdd(p.dWl + g * H + hcol, accl[r]);
+            }
+        }
+    }
+}
+
+int check_mm(const AttnMM& p, const char* who) {
+    DCLIP_REQUIRE(p.A && p.Bm && p.C, "%s: null operand", who);
+    DCLIP_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.N <= NMAX, "%s: need 0 < N <= %d (N=%d)", who, NMAX, p.N);
+    DCLIP_REQUIRE(p.hd == 32 || p.hd == 64, "%s: head dim must be 32 or 64 (got %d)", who, p.hd);
+    DCLIP_REQUIRE(p.Np % 8 == 0 && p.Np >= p.N, "%s: Np must be a multiple of 8 and >= N", who);
+    return DCLIP_OK;
+}
+
+}  // namespace
+
+extern "C" int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B,
+                             int64_t H, int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
+    AttnMM p{A, lda, (const bf16_t*)Bm, ldb, C, Np, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+    if (int rc = check_mm(p, "dclip_attn_nt")) return rc;
+    DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "dclip_attn_nt: token-major strides must be multiples of 8");
+    const dim3 grid((unsigned)((B * H + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 32) {
+        if (out_f32) hipLaunchKernelGGL((attn_nt_kernel<32, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_nt_kernel<32, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (out_f32) hipLaunchKernelGGL((attn_nt_kernel<64, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_nt_kernel<64, false>), grid, dim3(256), 0, st, p);
+    }
+    return dclip_check_launch("dclip_attn_nt");
+}
+
+extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H,
+                             int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
+    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+    if (int rc = check_mm(p, "dclip_attn_nn")) return rc;
+    const dim3 grid((unsigned)((B * H + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 32) hipLaunchKernelGGL((attn_nn_kernel<32>), grid, dim3(256), 4 * NMAX * (32 * 2 + 32), st, p);
+    else hipLaunchKernelGGL((attn_nn_kernel<64>), grid, dim3(256), 4 * NMAX * (64 * 2 + 32), st, p);
+    return dclip_check_launch("dclip_attn_nn");
+}
+
+extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H,
+                             int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
+    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+    if (int rc = check_mm(p, "dclip_attn_tn")) return rc;
+    const dim3 grid((unsigned)((B * H + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 32) hipLaunchKernelGGL((attn_tn_kernel<32>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (32 * 2 + 32)), st, p);
+    else hipLaunchKernelGGL((attn_tn_kernel<64>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (64 * 2 + 32)), st, p);
+    return dclip_check_launch("dclip_attn_tn");
+}
+
+#define SM_DISPATCH_H(Hv, NSv, ...)                                               \
+    switch (Hv) {                                                                 \
+        case 2: { constexpr int HH = 2; SM_DISPATCH_NS(NSv, __VA_ARGS__); break; }   \
+        case 4: { constexpr int HH = 4; SM_DISPATCH_NS(NSv, __VA_ARGS__); break; }   \
+        case 8: { constexpr int HH = 8; SM_DISPATCH_NS(NSv, __VA_ARGS__); break; }   \
+        case 12: { constexpr int HH = 12; SM_DISPATCH_NS(NSv, __VA_ARGS__); break; } \
+        case 24: { constexpr int HH = 24; SM_DISPATCH_NS(NSv, __VA_ARGS__); break; } \
+        default: dclip_set_error("attention softmax: unsupported head count %d (2/4/8/12/24)", (int)(Hv)); return DCLIP_EINVAL; \
+    }
+#define SM_DISPATCH_NS(NSv, ...)                              \
+    if ((NSv) == 1) { constexpr int NSS = 1; __VA_ARGS__; }   \
+    else { constexpr int NSS = 2; __VA_ARGS__; }
+
+extern "C" int dclip_attn_softmax_fwd(const float* S, const float* Wl, const float* Ww, void* P, void* R, int64_t B, int64_t H,
+                                      int64_t N, int64_t Np, int causal, void* stream) {
+    DCLIP_REQUIRE(S && R && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_softmax_fwd: bad argument");
+    DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_fwd: conv_l and conv_w come together");
+    SoftmaxFwd p{S, Wl, Ww, (bf16_t*)P, (bf16_t*)R, (int)B, (int)N, (int)Np, causal};
+    const dim3 grid((unsigned)((B * N + 3) / 4));
+    const int ns = N > 64 ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_fwd_kernel<HH, NSS>), grid, dim3(256), 0, st, p));
+    return dclip_check_launch("dclip_attn_softmax_fwd");
+}
+
+extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const float* Wl, const float* Ww, void* dS,
+                                      float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np, void* stream) {
+    DCLIP_REQUIRE(dR && P && dS && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_softmax_bwd: bad argument");
+    DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_bwd: conv_l and conv_w come together");
+    DCLIP_REQUIRE(!Wl || S, "dclip_attn_softmax_bwd: raw scores needed for dW_l");
+    SoftmaxBwd p{(const bf16_t*)dR, (const bf16_t*)P, S, Wl, Ww, (bf16_t*)dS, dWl, dWw, (int)B, (int)N, (int)Np};
+    int blocks = (int)((B * N + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    const int ns = N > 64 ? 2 : 1;
+    const size_t lds = 4 * 2 * 32 * (64 * ns * 2 + 16);
+    hipStream_t st = (hipStream_t)stream;
+    SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
+    return dclip_check_launch("dclip_attn_softmax_bwd");
+}

@@ -1,0 +1,270 @@
+// HBM-bound helper kernels around the GEMMs: dtype casts / weight transposes, im2row for the patch embedding,
+// token-embedding gather / scatter-add, positional / class-token tables and their gradients, EOT pick indices.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4*)(s + i);
+            bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            *(bf16x4*)(d + i) = o;
+        } else {
+            for (int64_t j = i; j < n; ++j) d[j] = f2bf(s[j]);
+        }
+    }
+}
+
+// W f32 [R,C] -> Wb bf16 [R,C] and Wt bf16 [C,R]; 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wb,
+                                                             bf16_t* __restrict__ Wt, int R, int C) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16_t v = f2bf(0.f);
+        if (r < R && c < C) {
+            v = f2bf(W[(int64_t)r * C + c]);
+            if (Wb) Wb[(int64_t)r * C + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (Wt)
+        for (int i = ty; i < 64; i += 4) {
+            const int c = c0 + i, r = r0 + tx;
+            if (r < R && c < C) Wt[(int64_t)c * R + r] = tile[tx][i];
+        }
+}
+
+// img f32 [B,C,res,res] -> rows bf16 [B*(G*G+cls), C*p*p]; row (b, cls + py*G + px), col (c, ky, kx)
+// (reference _common.py:196-198 / timm PatchEmbed: Conv2d(k=p, s=p) == im2row + GEMM; the trailing res % p pixels
+// are dropped exactly like the strided conv does).  cls rows are zero so the GEMM emits 0 there.
+__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C,
+                                                     int res, int p, int G, int cls) {
+    const int K = C * p * p;
+    const int kq = K / 4;                       // float4 chunks per row
+    const int rows = B * (G * G + cls);
+    const int64_t total = (int64_t)rows * kq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / kq), q = (int)(i % kq);
+        const int b = row / (G * G + cls), t = row % (G * G + cls);
+        bf16x4 o = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        if (t >= cls) {
+            const int pi = t - cls, py = pi / G, px = pi % G;
+            const int k = q * 4, c = k / (p * p), ky = (k / p) % p, kx = k % p;
+            const float4 v = *(const float4*)(img + (((int64_t)b * C + c) * res + (py * p + ky)) * res + px * p + kx);
+            o = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+        }
+        *(bf16x4*)(out + (int64_t)row * K + q * 4) = o;
+    }
+}
+
+// out[0] = pos[0] + cls ; out[n>=1] = pos[n] + bias      (cls / bias may be null)
+__global__ void token_table_kernel(const float* __restrict__ pos, const float* __restrict__ cls,
+                                   const float* __restrict__ bias, float* __restrict__ out, int ntok, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntok * D) return;
+    const int n = i / D, c = i % D;
+    float v = pos[i];
+    if (cls) v += (n == 0) ? cls[c] : (bias ? bias[c] : 0.f);
+    else if (bias) v += bias[c];
+    out[i] = v;
+}
+
+// tok_sum[n] = sum_b G[b,n,:]  ->  dpos += tok_sum ; dcls += tok_sum[0] ; dbias += sum_{n>=cls} tok_sum[n]
+__global__ void token_table_bwd_kernel(const float* __restrict__ ts, float* __restrict__ dpos, float* __restrict__ dcls,
+                                       float* __restrict__ dbias, int ntok, int D, int has_cls) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float sb = 0.f;
+    for (int n = 0; n < ntok; ++n) {
+        const float v = ts[n * D + c];
+        if (dpos) dpos[n * D + c] += v;
+        if (n >= has_cls) sb += v;
+    }
+    if (dcls && has_cls) dcls[c] += ts[c];
+    if (dbias) dbias[c] += sb;
+}
+
+// out[n,:] += sum_b G[b,n,:]   grid (ceil(D/256), N, bsplit)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ G, float* __restrict__ out, int B, int N,
+                                                        int D, int per) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const int n = blockIdx.y;
+    const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += G[((int64_t)b * N + n) * D + c];
+    unsafeAtomicAdd(out + (int64_t)n * D + c, s);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, void* __restrict__ out, int rows,
+                                                           int N, int D) {
+    const int dq = D / 4;
+    const int64_t total = (int64_t)rows * dq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / dq), q = (int)(i % dq);
+        float4 v = *(const float4*)(table + ids[r] * D + q * 4);
+        if (pos) {
+            const float4 pv = *(const float4*)(pos + (int64_t)(r % N) * D + q * 4);
+            v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+        }
+        if (OUT_F32) *(float4*)((float*)out + (int64_t)r * D + q * 4) = v;
+        else *(bf16x4*)((bf16_t*)out + (int64_t)r * D + q * 4) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    }
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const void* __restrict__ dx,
+                                                            float* __restrict__ dtable, int rows, int D) {
+    const int64_t total = (int64_t)rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / D), c = (int)(i % D);
+        const float v = IN_F32 ? ((const float*)dx)[i] : bf2f(((const bf16_t*)dx)[i]);
+        unsafeAtomicAdd(dtable + ids[r] * D + c, v);
+    }
+}
+
+// idx[b] = b*N + argmax_n ids[b,n] (first maximum, like torch.argmax) ; ids == null -> b*N (class-token row)
+__global__ void pick_index_kernel(const int64_t* __restrict__ ids, int* __restrict__ idx, int B, int N) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int best = 0;
+    if (ids) {
+        int64_t m = ids[(int64_t)b * N];
+        for (int n = 1; n < N; ++n) {
+            const int64_t v = ids[(int64_t)b * N + n];
+            if (v > m) { m = v; best = n; }
+        }
+    }
+    idx[b] = b * N + best;
+}
+
+// out[r, :] = src[idx[r], :]   (f32 rows)
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds, const int* __restrict__ idx,
+                                   float* __restrict__ out, int rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * D) return;
+    const int r = (int)(i / D), c = (int)(i % D);
+    out[i] = src[(int64_t)idx[r] * lds + c];
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay; bias-corrected), reference distil_model.py:160-162
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+inline int grid_for(int64_t work, int per_block = 256, int cap = 2048 * 4) {
+    int64_t g = (work + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    DCLIP_REQUIRE(src && dst && n > 0, "dclip_cast_bf16: bad argument");
+    DCLIP_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "dclip_cast_bf16: misaligned buffer");
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    return dclip_check_launch("dclip_cast_bf16");
+}
+
+extern "C" int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream) {
+    DCLIP_REQUIRE(W && (Wb || Wt) && R > 0 && C > 0, "dclip_cast_transpose_bf16: bad argument");
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+    hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)Wb, (bf16_t*)Wt, (int)R, (int)C);
+    return dclip_check_launch("dclip_cast_transpose_bf16");
+}
+
+extern "C" int dclip_im2row(const float* img, void* rows, int64_t B, int64_t C, int64_t res, int64_t patch, int cls_rows,
+                            void* stream) {
+    DCLIP_REQUIRE(img && rows && B > 0 && C > 0 && res >= patch && patch > 0, "dclip_im2row: bad argument");
+    DCLIP_REQUIRE(patch % 4 == 0 && res % 4 == 0, "dclip_im2row: patch and resolution must be multiples of 4");
+    DCLIP_REQUIRE(cls_rows == 0 || cls_rows == 1, "dclip_im2row: cls_rows must be 0 or 1");
+    const int G = (int)(res / patch);
+    const int64_t work = B * (G * G + cls_rows) * (C * patch * patch / 4);
+    hipLaunchKernelGGL(im2row_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)rows, (int)B,
+                       (int)C, (int)res, (int)patch, G, cls_rows);
+    return dclip_check_launch("dclip_im2row");
+}
+
+extern "C" int dclip_token_table(const float* pos, const float* cls, const float* bias, float* out, int64_t ntok, int64_t D,
+                                 void* stream) {
+    DCLIP_REQUIRE(pos && out && ntok > 0 && D > 0, "dclip_token_table: bad argument");
+    hipLaunchKernelGGL(token_table_kernel, dim3((unsigned)((ntok * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, cls,
+                       bias, out, (int)ntok, (int)D);
+    return dclip_check_launch("dclip_token_table");
+}
+
+extern "C" int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D,
+                                     int has_cls, void* stream) {
+    DCLIP_REQUIRE(tok_sum && ntok > 0 && D > 0, "dclip_token_table_bwd: bad argument");
+    hipLaunchKernelGGL(token_table_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok_sum,
+                       dpos, dcls, dbias, (int)ntok, (int)D, has_cls);
+    return dclip_check_launch("dclip_token_table_bwd");
+}
+
+extern "C" int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_t D, void* stream) {
+    DCLIP_REQUIRE(G && out && B > 0 && N > 0 && D > 0, "dclip_batch_sum_acc: bad argument");
+    const int per = 32;
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)N, (unsigned)((B + per - 1) / per));
+    hipLaunchKernelGGL(batch_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, out, (int)B, (int)N, (int)D, per);
+    return dclip_check_launch("dclip_batch_sum_acc");
+}
+
+extern "C" int dclip_embed_gather(const int64_t* ids, const float* table, const float* pos, void* out, int out_f32,
+                                  int64_t rows, int64_t N, int64_t D, void* stream) {
+    DCLIP_REQUIRE(ids && table && out && rows > 0 && N > 0 && D > 0 && D % 4 == 0, "dclip_embed_gather: bad argument");
+    const dim3 grid(grid_for(rows * D / 4));
+    if (out_f32) hipLaunchKernelGGL((embed_gather_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, table, pos, out, (int)rows, (int)N, (int)D);
+    else hipLaunchKernelGGL((embed_gather_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, table, pos, out, (int)rows, (int)N, (int)D);
+    return dclip_check_launch("dclip_embed_gather");
+}
+
+extern "C" int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
+                                       void* stream) {
+    DCLIP_REQUIRE(ids && dx && dtable && rows > 0 && D > 0, "dclip_embed_scatter_add: bad argument");
+    const dim3 grid(grid_for(rows * D));
+    if (dx_f32) hipLaunchKernelGGL((embed_scatter_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, dx, dtable, (int)rows, (int)D);
+    else hipLaunchKernelGGL((embed_scatter_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, dx, dtable, (int)rows, (int)D);
+    return dclip_check_launch("dclip_embed_scatter_add");
+}
+
+extern "C" int dclip_pick_index(const int64_t* ids, int32_t* idx, int64_t B, int64_t N, void* stream) {
+    DCLIP_REQUIRE(idx && B > 0 && N > 0, "dclip_pick_index: bad argument");
+    hipLaunchKernelGGL(pick_index_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, idx, (int)B, (int)N);
+    return dclip_check_launch("dclip_pick_index");
+}
+
+extern "C" int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D,
+                                 void* stream) {
+    DCLIP_REQUIRE(src && idx && out && rows > 0 && D > 0, "dclip_gather_rows: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, idx, out, (int)rows, (int)D);
+    return dclip_check_launch("dclip_gather_rows");
+}
+
+extern "C" int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int64_t step, void* stream) {
+    DCLIP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dclip_adamw: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2);
+    return dclip_check_launch("dclip_adamw");
+}

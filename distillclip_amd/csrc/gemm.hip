@@ -121,12 +121,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
                 const int row = rowb + i * 16 + r;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha + bias;
-                int64_t orow = row;
-                if (p.row_group > 0) {
-                    const int g = row / p.row_group, w = row - g * p.row_group;
-                    orow = row + g + 1;
-                    v += p.rowadd[(int64_t)(w + 1) * p.N + col];
-                }
+                const int64_t orow = row;
+                if (p.row_group > 0) v += p.rowadd[(int64_t)(row % p.row_group) * p.N + col];
                 const int64_t o = orow * p.ldc + col;
                 if (p.aux_out) p.aux_out[o] = f2bf(v);
                 if (ACT == 1) v = quick_gelu_f(v);

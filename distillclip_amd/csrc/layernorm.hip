@@ -1,0 +1,177 @@
+// LayerNorm forward / backward (fp32 statistics, eps inside the sqrt), HBM-bound.
+//   reference: model/component/_common.py:14-20 (fp32 LayerNorm), nn.LayerNorm in weight_share_model.py:239,
+//   call sites _common.py:123,125,208,210 ; text_encoder.py:69 ; weight_share_model.py:181,183,363,503.
+// One wave per row, the row lives in registers (float4 chunks, D <= 1024), two-pass mean / variance.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;   // float4 chunks per lane: D <= 64 * 4 * 4 = 1024
+
+template <int NV, bool OUT_F32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int* __restrict__ ridx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     void* __restrict__ y, int64_t ldy, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t src = ridx ? ridx[row] : row;
+    const float* xr = x + src * ldx;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *(const float4*)(xr + c) : float4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
+            const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
+            if (OUT_F32) {
+                *(float4*)((float*)y + (int64_t)row * ldy + c) = float4{o0, o1, o2, o3};
+            } else {
+                bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
+                *(bf16x4*)((bf16_t*)y + (int64_t)row * ldy + c) = o;
+            }
+        }
+    }
+}
+
+// backward: dx_acc[row] += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//           dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy       (per-wave register partials -> LDS -> atomics)
+template <int NV, bool DY_F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                     int64_t ldx, const int* __restrict__ ridx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx_acc,
+                                                     int64_t lddx, bf16_t* __restrict__ dx_bf16, int64_t lddb,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+    __shared__ float red[2][4][LN_MAXV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = db[i] = float4{0.f, 0.f, 0.f, 0.f};
+        const int c = (i * 64 + lane) * 4;
+        gm[i] = c < D ? *(const float4*)(gamma + c) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const int64_t src = ridx ? ridx[row] : row;
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                const float4 xv = *(const float4*)(x + src * ldx + c);
+                float4 d;
+                if (DY_F32) d = *(const float4*)((const float*)dy + (int64_t)row * lddy + c);
+                else {
+                    const bf16x4 t = *(const bf16x4*)((const bf16_t*)dy + (int64_t)row * lddy + c);
+                    d = float4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+                }
+                xh[i] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+                g[i] = float4{d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w};
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+                db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                float* o = dx_acc + src * lddx + c;
+                float4 a = *(const float4*)o;
+                a.x += rs * (g[i].x - c1 - xh[i].x * c2);
+                a.y += rs * (g[i].y - c1 - xh[i].y * c2);
+                a.z += rs * (g[i].z - c1 - xh[i].z * c2);
+                a.w += rs * (g[i].w - c1 - xh[i].w * c2);
+                *(float4*)o = a;
+                if (dx_bf16) {
+                    bf16x4 b = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+                    *(bf16x4*)(dx_bf16 + src * lddb + c) = b;
+                }
+            }
+        }
+    }
+    // block reduction of the parameter gradients, then one atomic per column per block
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        *(float4*)&red[0][wave][c] = dg[i];
+        *(float4*)&red[1][wave][c] = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        if (dgamma) unsafeAtomicAdd(dgamma + c, a);
+        if (dbeta) unsafeAtomicAdd(dbeta + c, b);
+    }
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NVV, ...)                     \
+    switch (NVV) {                                \
+        case 1: { constexpr int NV = 1; __VA_ARGS__; break; } \
+        case 2: { constexpr int NV = 2; __VA_ARGS__; break; } \
+        case 3: { constexpr int NV = 3; __VA_ARGS__; break; } \
+        default: { constexpr int NV = 4; __VA_ARGS__; break; } \
+    }
+
+extern "C" int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma,
+                                   const float* beta, void* y, int64_t ldy, int out_f32, float* mean, float* rstd,
+                                   int64_t M, int64_t D, float eps, void* stream) {
+    DCLIP_REQUIRE(x && gamma && beta && y, "dclip_layernorm_fwd: null operand");
+    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_fwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
+    DCLIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "dclip_layernorm_fwd: row strides must be multiples of 4");
+    const int nv = (int)((D + 255) / 256);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(nv,
+        if (out_f32) hipLaunchKernelGGL((ln_fwd_kernel<NV, true>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps);
+        else hipLaunchKernelGGL((ln_fwd_kernel<NV, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps));
+    return dclip_check_launch("dclip_layernorm_fwd");
+}
+
+extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx,
+                                   const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
+                                   float* dx_acc, int64_t lddx, void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta,
+                                   int64_t M, int64_t D, void* stream) {
+    DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx_acc, "dclip_layernorm_bwd: null operand");
+    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
+    const int nv = (int)((D + 255) / 256);
+    int blocks = (int)((M + 3) / 4);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(nv,
+        if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, (int)M, (int)D);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, (int)M, (int)D));
+    return dclip_check_launch("dclip_layernorm_bwd");
+}

@@ -56,3 +56,57 @@ def colsum_acc(x, db):
     assert x.dtype == torch.bfloat16 and db.dtype == torch.float32
     lib().dclip_colsum_acc(_p(x), x.stride(0), _p(db), x.shape[0], x.shape[1], _stream())
     return db
+
+
+def layernorm_fwd(x, gamma, beta, *, row_index=None, out_dtype=torch.bfloat16, eps=1e-5, save_stats=True):
+    _chk(x, gamma, beta, row_index)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M = row_index.numel() if row_index is not None else x.shape[0]
+    D = x.shape[1]
+    y = torch.empty((M, D), dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    lib().dclip_layernorm_fwd(_p(x), x.stride(0), _p(row_index), _p(gamma), _p(beta), _p(y), D,
+                              1 if out_dtype == torch.float32 else 0, _p(mean), _p(rstd), M, D, eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_acc, *, row_index=None, dx_bf16=None, dgamma=None, dbeta=None):
+    _chk(dy, x, gamma, mean, rstd, dx_acc, dx_bf16, dgamma, dbeta)
+    M, D = dy.shape
+    lib().dclip_layernorm_bwd(_p(dy), dy.stride(0), 1 if dy.dtype == torch.float32 else 0, _p(x), x.stride(0),
+                              _p(row_index), _p(gamma), _p(mean), _p(rstd), _p(dx_acc), dx_acc.stride(0), _p(dx_bf16),
+                              dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(dgamma), _p(dbeta), M, D, _stream())
+
+
+def attn_nt(a, lda, bm, ldb, B, H, N, hd, alpha=1.0, out_dtype=torch.float32):
+    Np = (N + 7) // 8 * 8
+    c = torch.empty((B, H, N, Np), dtype=out_dtype, device=a.device)
+    lib().dclip_attn_nt(_p(a), lda, _p(bm), ldb, _p(c), 1 if out_dtype == torch.float32 else 0, B, H, N, Np, hd, alpha,
+                        _stream())
+    return c
+
+
+def attn_nn(a, bm, ldb, c, ldc, hd, alpha=1.0):
+    B, H, N, Np = a.shape
+    lib().dclip_attn_nn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, _stream())
+
+
+def attn_tn(a, bm, ldb, c, ldc, hd, alpha=1.0):
+    B, H, N, Np = a.shape
+    lib().dclip_attn_tn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, _stream())
+
+
+def attn_softmax_fwd(s, wl=None, ww=None, causal=False, save_p=False):
+    B, H, N, Np = s.shape
+    r = torch.empty((B, H, N, Np), dtype=torch.bfloat16, device=s.device)
+    p = torch.empty_like(r) if save_p else None
+    lib().dclip_attn_softmax_fwd(_p(s), _p(wl), _p(ww), _p(p), _p(r), B, H, N, Np, 1 if causal else 0, _stream())
+    return p, r
+
+
+def attn_softmax_bwd(dr, p, s, wl=None, ww=None, dwl=None, dww=None):
+    B, H, N, Np = dr.shape
+    ds = torch.empty_like(dr)
+    lib().dclip_attn_softmax_bwd(_p(dr), _p(p), _p(s), _p(wl), _p(ww), _p(ds), _p(dwl), _p(dww), B, H, N, Np, _stream())
+    return ds

@@ -40,9 +40,9 @@ const char* dclip_last_error_string(void);  /* thread-local */
  *   epilogue, in order: + bias[N] (f32, may be NULL) ; if aux_out: store pre-activation as bf16 [M,N] (ld = ldc) ;
  *   activation `act` (DCLIP_ACT_DGELU multiplies by gelu'(aux_in[M,N] bf16, ld = ldc)) ;
  *   + residual[M,N] (f32, ld = ldr, may be NULL, may alias C when out_f32) ; store C as f32 (out_f32=1) or bf16.
- *   row_group > 0 enables the patch-embedding row map (reference _common.py:196-202, weight_share_model.py:344-349):
- *   GEMM row r is stored at row r + r / row_group + 1 and `rowadd` (f32 [row_group + 1, N], the positional
- *   embedding) row (r % row_group) + 1 is added.
+ *   row_group > 0 adds `rowadd` (f32 [row_group, N]) row (r % row_group) to GEMM row r: the positional-embedding
+ *   add of the token embedders (reference _common.py:196-202, text_encoder.py:65-66, weight_share_model.py:344-349,
+ *   :487-489); for images the caller folds class token and conv bias into the table (see dclip_token_table).
  */
 int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
@@ -60,6 +60,76 @@ int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, fl
 
 /* db[N] (f32) += column sums of X[M,N] (bf16, ld) — bias gradient of nn.Linear. */
 int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 statistics, eps inside the sqrt).
+ *   reference: model/component/_common.py:14-20 (call sites :123,:125,:208,:210 ; text_encoder.py:69) and nn.LayerNorm in
+ *   weight_share_model.py:181,183,363,503.
+ * fwd: y[r] = LN(x[row_index ? row_index[r] : r]) * gamma + beta ; y is bf16 (out_f32=0) or f32 ; mean/rstd (f32 [M],
+ *      nullable) are saved for backward.  D % 4 == 0, D <= 1024.
+ * bwd: dx_acc[src(r)] += LN'(dy[r]) (f32, in place: the residual-stream gradient) ; optional bf16 copy of the updated
+ *      rows in dx_bf16 ; dgamma / dbeta (f32 [D], nullable) += batch sums.
+ */
+int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                        void* y, int64_t ldy, int out_f32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                        void* stream);
+int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx, const int32_t* row_index,
+                        const float* gamma, const float* mean, const float* rstd, float* dx_acc, int64_t lddx,
+                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t M, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Attention building blocks.  q/k/v/ctx are token-major bf16 (row = b*N + n, column = head*hd + d, row stride ld*);
+ * score-like tensors are [B,H,N,Np], Np = round_up(N, 8), pad columns zero.  hd in {32, 64}, N <= 128.
+ *   reference teacher: _common.py:73-89 ; student: weight_share_model.py:101-125 (scale, QK^T, conv_l, softmax,
+ *   conv_w, PV) ; causal mask: text_encoder.py:54-60.
+ * nt : C[b,h,i,j] = alpha * sum_d A[(b,i),h*hd+d] * Bm[(b,j),h*hd+d]          (S = QK^T ; dR = dO V^T)
+ * nn : C[(b,i),h*hd+d] = alpha * sum_j A[b,h,i,j] * Bm[(b,j),h*hd+d]          (O = R V ; dQ = dS K)
+ * tn : C[(b,j),h*hd+d] = alpha * sum_i A[b,h,i,j] * Bm[(b,i),h*hd+d]          (dV = R^T dO ; dK = dS^T Q)
+ * softmax_fwd : A_g = sum_h Wl[g,h] S_h ; P = softmax_j(A) (causal: j <= i) ; R_g = sum_h Ww[g,h] P_h.
+ *               Wl/Ww NULL = plain multi-head softmax (teacher).  P (nullable) is saved for backward.
+ * softmax_bwd : dS from dR (+ dWl, dWw += H x H weight gradients, f32).
+ */
+int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B, int64_t H,
+                  int64_t N, int64_t Np, int64_t hd, float alpha, void* stream);
+int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
+                  int64_t Np, int64_t hd, float alpha, void* stream);
+int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
+                  int64_t Np, int64_t hd, float alpha, void* stream);
+int dclip_attn_softmax_fwd(const float* S, const float* Wl, const float* Ww, void* P, void* R, int64_t B, int64_t H,
+                           int64_t N, int64_t Np, int causal, void* stream);
+int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const float* Wl, const float* Ww, void* dS,
+                           float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Embedding-side helpers (HBM-bound).
+ * cast_bf16            : f32 -> bf16 copy (per-step weight down-cast).
+ * cast_transpose_bf16  : W f32 [R,C] -> Wb bf16 [R,C] (nullable) and Wt bf16 [C,R] (nullable; the dgrad operand).
+ * im2row               : image f32 [B,C,res,res] -> bf16 rows [B*(G*G+cls_rows), C*p*p], G = res / p; the class-token row
+ *                        is zero.  Conv2d(k=p,s=p) of _common.py:176,196 / timm PatchEmbed (weight_share_model.py:250).
+ * token_table          : out[0] = pos[0] + cls ; out[n>=1] = pos[n] + bias  (cls NULL: out[n] = pos[n] + bias)
+ *                        (_common.py:199-202 ; weight_share_model.py:346-349, :489) ; token_table_bwd is its adjoint given
+ *                        tok_sum[n] = sum_b G[b,n,:] from batch_sum_acc.
+ * embed_gather         : out[r] = table[ids[r]] + pos[r % N] (text_encoder.py:65-66 ; weight_share_model.py:487-489).
+ * embed_scatter_add    : dtable[ids[r]] += dx[r] (f32 atomics).
+ * pick_index           : idx[b] = b*N + argmax_n ids[b,n] (text_encoder.py:86, weight_share_model.py:506); ids NULL: b*N.
+ * gather_rows          : out[r] = src[idx[r]] (f32).
+ * adamw                : torch.optim.AdamW step on flat f32 buffers (distil_model.py:160-162, dual_distill_model.py:194-196).
+ */
+int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream);
+int dclip_im2row(const float* img, void* rows, int64_t B, int64_t C, int64_t res, int64_t patch, int cls_rows, void* stream);
+int dclip_token_table(const float* pos, const float* cls, const float* bias, float* out, int64_t ntok, int64_t D, void* stream);
+int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D, int has_cls,
+                          void* stream);
+int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_t D, void* stream);
+int dclip_embed_gather(const int64_t* ids, const float* table, const float* pos, void* out, int out_f32, int64_t rows,
+                       int64_t N, int64_t D, void* stream);
+int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
+                            void* stream);
+int dclip_pick_index(const int64_t* ids, int32_t* idx, int64_t B, int64_t N, void* stream);
+int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D, void* stream);
+int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,135 @@
+"""GPU parity of the LayerNorm / embedding / attention kernels against torch fp32 on identical (bf16-rounded) inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _randn(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _close(got, ref, tol, what=''):
+    err = (got.float() - ref.float()).abs().max().item()
+    den = ref.float().abs().max().item() + 1e-9
+    assert err / den < tol, (what, err, den)
+
+
+@pytest.mark.parametrize('M,D', [(7, 128), (1000, 768), (513, 512), (64, 1024)])
+def test_layernorm_fwd_bwd(M, D):
+    from distillclip_amd import ops
+    x = _randn((M, D), 1, 2.0) + 0.5
+    g, b = _randn((D,), 2, 0.1) + 1, _randn((D,), 3, 0.1)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    _close(y, ref, 5e-3, 'y bf16')
+    y32, _, _ = ops.layernorm_fwd(x, g, b, out_dtype=torch.float32)
+    _close(y32, ref, 2e-6, 'y f32')
+    dy = _randn((M, D), 4).to(torch.bfloat16)
+    ref.backward(dy.float())
+    acc0 = _randn((M, D), 5)
+    acc = acc0.clone()
+    dxb = torch.zeros(M, D, dtype=torch.bfloat16, device='cuda')
+    dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    ops.layernorm_bwd(dy, x, g, mean, rstd, acc, dx_bf16=dxb, dgamma=dg, dbeta=db)
+    _close(acc - acc0, xr.grad, 2e-5, 'dx')
+    _close(dxb, acc, 5e-3, 'dx bf16 copy')
+    _close(dg, gr.grad, 2e-5, 'dgamma')
+    _close(db, br.grad, 2e-5, 'dbeta')
+
+
+def test_layernorm_row_index():
+    from distillclip_amd import ops
+    x = _randn((40, 128), 1)
+    g, b = _randn((128,), 2) + 1, _randn((128,), 3)
+    idx = torch.tensor([3, 17, 39, 0], dtype=torch.int32, device='cuda')
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, row_index=idx, out_dtype=torch.float32)
+    _close(y, F.layer_norm(x[idx.long()], (128,), g, b), 2e-6)
+    dy = _randn((4, 128), 4)
+    acc = torch.zeros_like(x)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, acc, row_index=idx)
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr[idx.long()], (128,), g, b).backward(dy)
+    _close(acc, xr.grad, 2e-5)
+
+
+def _qkv(B, N, H, hd, seed):
+    D = H * hd
+    return _randn((B * N, 3 * D), seed, 1.0, torch.bfloat16)
+
+
+def _heads(t, B, N, H, hd):
+    return t.float().view(B, N, H, hd).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize('B,N,H,hd', [(3, 17, 4, 32), (2, 13, 2, 64), (5, 50, 24, 32), (3, 77, 12, 64), (2, 101, 12, 64),
+                                      (2, 77, 8, 64)])
+def test_attention_products(B, N, H, hd):
+    from distillclip_amd import ops
+    D = H * hd
+    qkv = _qkv(B, N, H, hd, 7)
+    q, k, v = (_heads(qkv[:, i * D:(i + 1) * D], B, N, H, hd) for i in range(3))
+    scale = hd ** -0.5
+    # NT: scores
+    s = ops.attn_nt(qkv, 3 * D, qkv[:, D:], 3 * D, B, H, N, hd, alpha=scale)
+    ref_s = q @ k.transpose(-1, -2) * scale
+    _close(s[..., :N], ref_s, 1e-5, 'scores')
+    assert torch.count_nonzero(s[..., N:]) == 0
+    # NN: context from an arbitrary bf16 "probability" tensor
+    Np = s.shape[-1]
+    r = torch.zeros(B, H, N, Np, dtype=torch.bfloat16, device='cuda')
+    r[..., :N] = _randn((B, H, N, N), 8, 0.3, torch.bfloat16)
+    ctx = torch.zeros(B * N, D, dtype=torch.bfloat16, device='cuda')
+    ops.attn_nn(r, qkv[:, 2 * D:], 3 * D, ctx, D, hd)
+    ref_ctx = (r[..., :N].float() @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    _close(ctx, ref_ctx, 6e-3, 'ctx')
+    # TN: dV = R^T dO
+    do = _randn((B * N, D), 9, 1.0, torch.bfloat16)
+    dv = torch.zeros(B * N, D, dtype=torch.bfloat16, device='cuda')
+    ops.attn_tn(r, do, D, dv, D, hd, alpha=0.5)
+    ref_dv = 0.5 * (r[..., :N].float().transpose(-1, -2) @ _heads(do, B, N, H, hd)).permute(0, 2, 1, 3).reshape(B * N, D)
+    _close(dv, ref_dv, 6e-3, 'dv')
+
+
+@pytest.mark.parametrize('B,N,H,mix,causal', [(3, 17, 4, True, False), (2, 13, 2, True, False), (4, 50, 24, True, False),
+                                              (3, 77, 12, True, False), (3, 77, 8, False, True), (2, 50, 12, False, False),
+                                              (2, 101, 12, False, False)])
+def test_attention_softmax_stage(B, N, H, mix, causal):
+    from distillclip_amd import ops
+    Np = (N + 7) // 8 * 8
+    s = torch.zeros(B, H, N, Np, device='cuda')
+    s[..., :N] = _randn((B, H, N, N), 11, 1.5)
+    wl = (torch.eye(H, device='cuda') + _randn((H, H), 12, 0.2)) if mix else None
+    ww = (torch.eye(H, device='cuda') + _randn((H, H), 13, 0.2)) if mix else None
+    p, r = ops.attn_softmax_fwd(s, wl, ww, causal=causal, save_p=True)
+
+    sr = s[..., :N].clone().requires_grad_(True)
+    wlr = wl.clone().requires_grad_(True) if mix else None
+    wwr = ww.clone().requires_grad_(True) if mix else None
+    a = torch.einsum('gh,bhij->bgij', wlr, sr) if mix else sr
+    if causal:
+        a = a + torch.full((N, N), float('-inf'), device='cuda').triu_(1)
+    pr = a.softmax(-1)
+    rr = torch.einsum('gh,bhij->bgij', wwr, pr) if mix else pr
+    _close(p[..., :N], pr, 5e-3, 'P')
+    _close(r[..., :N], rr, 5e-3, 'R')
+    assert torch.count_nonzero(r[..., N:]) == 0 and torch.count_nonzero(p[..., N:]) == 0
+
+    # backward: feed the kernel the bf16 P it saved; compare against autograd of the fp32 graph
+    dr = torch.zeros(B, H, N, Np, dtype=torch.bfloat16, device='cuda')
+    dr[..., :N] = _randn((B, H, N, N), 14, 1.0, torch.bfloat16)
+    rr.backward(dr[..., :N].float())
+    dwl = torch.zeros(H, H, device='cuda') if mix else None
+    dww = torch.zeros(H, H, device='cuda') if mix else None
+    ds = ops.attn_softmax_bwd(dr, p, s, wl, ww, dwl, dww)
+    _close(ds[..., :N], sr.grad, 1.5e-2, 'dS')
+    assert torch.count_nonzero(ds[..., N:]) == 0
+    if mix:
+        _close(dww, wwr.grad, 3e-2, 'dWw')
+        _close(dwl, wlr.grad, 3e-2, 'dWl')   # bf16 dA / S operands; few positions at the tiny sizes
