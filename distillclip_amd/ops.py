@@ -110,3 +110,29 @@ def attn_softmax_bwd(dr, p, s, wl=None, ww=None, dwl=None, dww=None):
     ds = torch.empty_like(dr)
     lib().dclip_attn_softmax_bwd(_p(dr), _p(p), _p(s), _p(wl), _p(ww), _p(ds), _p(dwl), _p(dww), B, H, N, Np, _stream())
     return ds
+
+
+LOSS_SLOTS = {'out_l1': 0, 'out_cos': 1, 'out_kl': 2, 'out_ce': 3, 'cos_diff': 4, 'hard_label': 5, 'soft_label': 6,
+              'logits_mse': 7}
+
+
+def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=None):
+    """Fused loss fwd+bwd.  weights: {term: scale*percent}.  -> (scalars[16] device tensor, d_s_img, d_s_txt)."""
+    import ctypes
+    _chk(s_img, t_img, s_txt, t_txt)
+    B, E = s_img.shape
+    two = s_txt is not None
+    cfg = [0.0] * 10
+    for k, w in weights.items():
+        cfg[LOSS_SLOTS[k]] = float(w)
+    cfg[8] = float(temperature or 0.0)
+    cfg[9] = 1.0 if two else 0.0
+    cfg_arr = (ctypes.c_float * 10)(*cfg)
+    ws_bytes = lib().dclip_distill_loss_workspace(B, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s_img.device)
+    out = torch.empty(16, dtype=torch.float32, device=s_img.device)
+    d_i = torch.empty_like(s_img)
+    d_t = torch.empty_like(s_txt) if two else None
+    lib().dclip_distill_loss(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, ctypes.cast(cfg_arr, ctypes.c_void_p),
+                             _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
+    return out, d_i, d_t

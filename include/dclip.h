@@ -131,6 +131,26 @@ int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* o
 int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int64_t step, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused distillation loss, forward + backward.
+ *   reference: model/_loss.py:118-202 (cal_tow_tower_loss / cal_one_tower_loss), model/component/clip_model.py:37-44,
+ *   model/loss_component/{out_l1,out_cos,out_kl,out_ce,clip_cos_diff,hard_label,soft_label,logits_mse}.py.
+ * s_*, t_*: student / teacher last_representation, f32 [B,E] (E % 16 == 0, E <= 1024, B <= 4096).
+ * cfg (HOST pointer, 10 floats): w_out_l1, w_out_cos, w_out_kl, w_out_ce, w_cos_diff, w_hard_label, w_soft_label,
+ *   w_logits_mse (each = loss_scale * percent of _loss.py:148-152,195-200; 0 disables), temperature, two_tower (0/1).
+ *   two_tower = 1: loss = 0.5 * (image_tower + text_tower) + cross-modal terms ; 0: tower 0 only (s_txt etc. ignored).
+ * out_scalars (device, 16 f32): [0] total ; [1..4] image out_l1, out_cos, out_kl, out_ce ; [5..8] text ; [9..12] cos_diff,
+ *   hard_label, soft_label, logits_mse — raw (un-scaled) term values.
+ * d_s_img / d_s_txt (f32 [B,E]): d total / d student embeddings (overwritten).  The [B,B] logits never reach HBM.
+ */
+size_t dclip_distill_loss_workspace(int64_t B, int64_t E);
+int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B, int64_t E,
+                       const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt, void* workspace,
+                       size_t ws_bytes, void* stream);
+/* feature MSE (hidden_rep_mse / embedding_mse: hidden_mse.py:9-17, embed_mse.py:9-10):
+ *   loss_acc[0] += coef * mean((s - t)^2) ; ds_acc (nullable) += coef * 2 (s - t) / n */
+int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, float* loss_acc, float* ds_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
