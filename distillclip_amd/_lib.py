@@ -24,8 +24,10 @@ def _parse_header(path=_HEADER):
     src = re.sub(r'//[^\n]*', '', src)
     src = re.sub(r'^\s*#[^\n]*$', '', src, flags=re.M)
     src = src.replace('extern "C" {', '')
+    src = re.sub(r'typedef\s+struct[^;{]*\{.*?\}[^;]*;', '', src, flags=re.S)
+    src = re.sub(r'typedef[^;]*;', '', src)
     protos = {}
-    for m in re.finditer(r'((?:const\s+)?(?:int|void|char|float|size_t|int64_t|int32_t)[\s\*]*?)\b(dclip_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'((?:const\s+)?(?:int|void|char|float|size_t|int64_t|int32_t|dclip_encoder)[\s\*]*?)\b(dclip_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
         protos[name] = (_ctype(ret), [] if args in ('', 'void') else [_ctype(a) for a in args.split(',')])
     return protos
@@ -37,7 +39,7 @@ def _ctype(decl):
         return ctypes.c_char_p if re.match(r'const\s+char\s*\*', decl) and decl.count('*') == 1 and \
             not re.search(r'\*\s*\w+$', decl) else ctypes.c_void_p
     toks = [t for t in re.split(r'\s+', decl) if t not in ('const', 'unsigned', 'struct')]
-    return _CT[toks[0]]
+    return None if toks[0] == 'void' else _CT[toks[0]]
 
 
 class DclipError(RuntimeError):

@@ -1,0 +1,428 @@
+// Tower-level runtime: one C call = the whole stream-ordered launch sequence of an encoder tower.
+//
+//   teacher (frozen CLIP):  reference model/component/_common.py:188-221 (VisionTransformer.forward),
+//                           model/component/text_encoder.py:62-92 (TextEncoder.encode_text)
+//   student (weight-shared MiniViT blocks): reference model/component/weight_share_model.py:336-372, :482-512
+//                           (forward_features), :199-218 (RepeatedMiniBlock), :179-185 (MiniBlock), :88-140 (MiniAttention)
+//
+// The handle is an immutable plan (shapes + workspace/weight-cache offsets).  All device memory is owned by the caller:
+//   params / grads : arrays of f32 device pointers in the canonical order documented in include/dclip.h
+//   wcache         : bf16 copies of the GEMM weights (W and, for the student, W^T for dgrad), refreshed by _prepare
+//   workspace      : activations; in training mode everything backward needs stays resident between the two calls
+// No allocation, no synchronisation, no global state: safe to call from the autograd thread and capturable in a hipGraph.
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+#define CK(expr)                      \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != DCLIP_OK) return _rc; \
+    } while (0)
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Bump {
+    char* base; size_t off;
+    explicit Bump(void* b) : base((char*)b), off(0) {}
+    template <class T> T* take(size_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += up256(n * sizeof(T));
+        return p;
+    }
+};
+
+// canonical parameter order (see include/dclip.h)
+enum { P_PER_TBLOCK = 12, P_PER_SBLOCK = 8, P_PER_SREPEAT = 6 };
+
+struct Plan {
+    dclip_encoder_cfg c;
+    int D, H, hd, N, Np, F, E, L, R, K;        // K = patch GEMM contraction (image)
+    bool student, image, compressed;
+    // parameter indices
+    int p_embed0;                              // first embedding parameter
+    int p_blocks;                              // first block parameter
+    int p_final;                               // norm / ln_post .. projection
+    int n_params;
+    // weight cache offsets (bf16 elements), -1 = absent
+    struct BlockW { int64_t qkv, qkv_t, proj, proj_t, fc1, fc1_t, fc2, fc2_t; };
+    std::vector<BlockW> bw;
+    int64_t w_embed, w_embed_t, w_head, w_head_t, w_total;
+};
+
+int64_t wtake(int64_t& off, int64_t n) { int64_t o = off; off += (n + 127) & ~(int64_t)127; return o; }
+
+bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
+    p.c = c;
+    p.student = c.kind == 1; p.image = c.modality == 0;
+    p.D = c.width; p.H = c.heads; p.N = c.tokens; p.F = c.mlp_dim; p.E = c.out_dim; p.L = c.layers; p.R = c.repeats;
+    if (c.kind < 0 || c.kind > 1 || c.modality < 0 || c.modality > 1) { dclip_set_error("encoder: bad kind/modality"); return false; }
+    if (p.D <= 0 || p.H <= 0 || p.D % p.H) { dclip_set_error("encoder: width %d not divisible by heads %d", p.D, p.H); return false; }
+    p.hd = p.D / p.H;
+    if (p.hd != 32 && p.hd != 64) { dclip_set_error("encoder: head dim %d unsupported (32 or 64)", p.hd); return false; }
+    if (p.D % 64 || p.F % 64 || p.E % 64 || p.D > 1024) { dclip_set_error("encoder: width/mlp/out dims must be multiples of 64, width <= 1024"); return false; }
+    if (p.N <= 0 || p.N > 128) { dclip_set_error("encoder: tokens must be in 1..128 (got %d)", p.N); return false; }
+    if (p.L <= 0 || p.R <= 0 || (!p.student && p.R != 1)) { dclip_set_error("encoder: bad layers/repeats"); return false; }
+    p.Np = (p.N + 7) & ~7;
+    p.compressed = !p.image && c.embed_rank > 0;
+    p.K = 0;
+    if (p.image) {
+        if (c.patch <= 0 || c.resolution < c.patch || c.in_chans <= 0) { dclip_set_error("encoder: bad patch geometry"); return false; }
+        const int g = c.resolution / c.patch;
+        if (g * g + 1 != p.N) { dclip_set_error("encoder: tokens %d != (res/patch)^2 + 1 = %d", p.N, g * g + 1); return false; }
+        p.K = c.in_chans * c.patch * c.patch;
+        if (p.K % 64) { dclip_set_error("encoder: in_chans*patch^2 = %d must be a multiple of 64", p.K); return false; }
+    } else {
+        if (c.vocab <= 0) { dclip_set_error("encoder: vocab required for text"); return false; }
+        if (p.compressed && c.embed_rank % 64) { dclip_set_error("encoder: embed_rank must be a multiple of 64"); return false; }
+    }
+    if (p.student && c.head_mix && p.H != 2 && p.H != 4 && p.H != 8 && p.H != 12 && p.H != 24) {
+        dclip_set_error("encoder: head count %d unsupported by the head-mixing kernels", p.H); return false;
+    }
+    // parameter order
+    int n = 0;
+    p.p_embed0 = 0;
+    if (p.student) n += p.image ? 4 : (p.compressed ? 4 : 2);     // see header
+    else n += p.image ? 5 : 2;
+    p.p_blocks = n;
+    n += p.student ? p.L * (P_PER_SBLOCK + p.R * P_PER_SREPEAT) : p.L * P_PER_TBLOCK;
+    p.p_final = n;
+    n += p.student ? 4 : 3;
+    p.n_params = n;
+    // weight cache
+    int64_t off = 0;
+    const int64_t D = p.D, F = p.F, E = p.E;
+    p.bw.resize(p.L);
+    for (int l = 0; l < p.L; ++l) {
+        auto& b = p.bw[l];
+        b.qkv = wtake(off, 3 * D * D); b.proj = wtake(off, D * D); b.fc1 = wtake(off, F * D); b.fc2 = wtake(off, D * F);
+        if (p.student) { b.qkv_t = wtake(off, 3 * D * D); b.proj_t = wtake(off, D * D); b.fc1_t = wtake(off, F * D); b.fc2_t = wtake(off, D * F); }
+        else b.qkv_t = b.proj_t = b.fc1_t = b.fc2_t = -1;
+    }
+    p.w_embed = p.w_embed_t = -1;
+    if (p.image) p.w_embed = wtake(off, D * p.K);
+    else if (p.compressed) { p.w_embed = wtake(off, D * c.embed_rank); p.w_embed_t = wtake(off, D * c.embed_rank); }
+    p.w_head = wtake(off, E * D);                                 // [E, D] (teacher: proj^T)
+    p.w_head_t = p.student ? wtake(off, E * D) : -1;              // [D, E]
+    p.w_total = off;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------------------
+struct ExecSave {          // per block execution (student training)
+    float* x_mid; float* mean1; float* rstd1; float* mean2; float* rstd2;
+    bf16_t *h1, *qkv, *P, *Rm, *ctx, *h2, *z, *u;
+    float* S;
+};
+
+struct Work {
+    // persistent
+    std::vector<float*> X;                 // residual stream: X[0] embedding output .. X[LR]
+    std::vector<ExecSave> ex;
+    bf16_t* patches;                       // image: [M, K] ; compressed text: [M, rank]
+    float* tok_table;                      // [N, D]
+    int32_t* pick;                         // [B]
+    float *meanf, *rstdf;                  // final LN stats [B]
+    bf16_t* hf;                            // [B, D]
+    // temporaries
+    float* x0;                             // teacher image pre-ln_pre tokens
+    float* G; bf16_t* Gb;                  // residual-stream gradient
+    bf16_t *dbig, *dh, *dqkv, *dR, *dS, *dout;
+    float* tok_sum; float* demb;           // [N, D] ; compressed: [M, rank] f32
+    size_t bytes;
+};
+
+void layout(const Plan& p, int64_t B, bool training, void* base, Work& w) {
+    Bump b(base);
+    const int64_t M = B * p.N, D = p.D, F = p.F, SN = B * p.H * p.N * p.Np;
+    const int nex = p.L * p.R;
+    const bool save = p.student && training;
+    w.X.assign(nex + 1, nullptr);
+    w.ex.assign(nex, ExecSave{});
+    // teacher / inference: a single ping-pong set reused by every block
+    ExecSave shared{};
+    float* xs = nullptr;
+    if (!save) {
+        xs = b.take<float>(M * D);
+        shared.x_mid = xs;   // in-place residual stream
+        shared.h1 = b.take<bf16_t>(M * D); shared.qkv = b.take<bf16_t>(M * 3 * D);
+        shared.S = b.take<float>(SN); shared.P = (p.student && p.c.head_mix) ? b.take<bf16_t>(SN) : nullptr;
+        shared.Rm = b.take<bf16_t>(SN);
+        shared.ctx = b.take<bf16_t>(M * D); shared.h2 = shared.h1; shared.z = nullptr; shared.u = b.take<bf16_t>(M * F);
+        shared.mean1 = shared.rstd1 = shared.mean2 = shared.rstd2 = nullptr;
+    }
+    for (int e = 0; e <= nex; ++e) w.X[e] = save ? b.take<float>(M * D) : xs;
+    for (int e = 0; e < nex; ++e) {
+        if (!save) { w.ex[e] = shared; continue; }
+        ExecSave& s = w.ex[e];
+        s.x_mid = b.take<float>(M * D);
+        s.mean1 = b.take<float>(M); s.rstd1 = b.take<float>(M); s.mean2 = b.take<float>(M); s.rstd2 = b.take<float>(M);
+        s.h1 = b.take<bf16_t>(M * D); s.qkv = b.take<bf16_t>(M * 3 * D);
+        s.S = b.take<float>(SN); s.P = b.take<bf16_t>(SN); s.Rm = p.c.head_mix ? b.take<bf16_t>(SN) : s.P;
+        s.ctx = b.take<bf16_t>(M * D); s.h2 = b.take<bf16_t>(M * D); s.z = b.take<bf16_t>(M * F); s.u = b.take<bf16_t>(M * F);
+    }
+    w.patches = p.image ? b.take<bf16_t>(M * p.K) : (p.compressed ? b.take<bf16_t>(M * p.c.embed_rank) : nullptr);
+    w.tok_table = b.take<float>((int64_t)p.N * D);
+    w.pick = b.take<int32_t>(B);
+    w.meanf = b.take<float>(B); w.rstdf = b.take<float>(B);
+    w.hf = b.take<bf16_t>(B * D);
+    w.x0 = (!p.student && p.image) ? b.take<float>(M * D) : nullptr;
+    if (save) {
+        w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
+        w.dbig = b.take<bf16_t>(M * F); w.dh = b.take<bf16_t>(M * D); w.dqkv = b.take<bf16_t>(M * 3 * D);
+        w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
+        w.tok_sum = b.take<float>((int64_t)p.N * D);
+        w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
+    } else {
+        w.G = nullptr; w.Gb = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr;
+    }
+    w.bytes = b.off;
+}
+
+inline const float* PF(const void* const* params, int i) { return (const float*)params[i]; }
+
+inline int wsplits(int64_t M, int64_t P, int64_t Q) {
+    const int64_t tiles = ((P + 127) / 128) * ((Q + 127) / 128);
+    int s = (int)((768 + tiles - 1) / tiles);
+    const int smax = (int)((M + 511) / 512);
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+}
+
+inline int gemm(const void* A, int64_t lda, const void* Bw, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                const float* bias, int act, const void* aux_in, void* aux_out, const float* res, int64_t ldr, int out_f32,
+                int64_t row_group, const float* rowadd, void* st) {
+    return dclip_gemm_nt(A, lda, Bw, ldb, C, ldc, M, N, K, 1.f, bias, act, aux_in, aux_out, res, ldr, out_f32, row_group, rowadd, st);
+}
+
+}  // namespace
+
+struct dclip_encoder { Plan p; };
+
+extern "C" dclip_encoder* dclip_encoder_create(const dclip_encoder_cfg* cfg) {
+    if (!cfg) { dclip_set_error("dclip_encoder_create: null cfg"); return nullptr; }
+    dclip_encoder* e = new (std::nothrow) dclip_encoder();
+    if (!e) { dclip_set_error("dclip_encoder_create: out of host memory"); return nullptr; }
+    if (!make_plan(*cfg, e->p)) { delete e; return nullptr; }
+    return e;
+}
+
+extern "C" void dclip_encoder_destroy(dclip_encoder* e) { delete e; }
+extern "C" int64_t dclip_encoder_num_params(const dclip_encoder* e) { return e ? e->p.n_params : -1; }
+extern "C" size_t dclip_encoder_wcache_bytes(const dclip_encoder* e) { return e ? up256((size_t)e->p.w_total * 2) : 0; }
+
+extern "C" size_t dclip_encoder_workspace_bytes(const dclip_encoder* e, int64_t B, int training) {
+    if (!e || B <= 0) return 0;
+    Work w;
+    layout(e->p, B, training != 0, nullptr, w);
+    return w.bytes;
+}
+
+// parameter index helpers -------------------------------------------------------------------------------------
+namespace {
+struct TB { int ln1w, ln1b, inw, inb, outw, outb, ln2w, ln2b, fcw, fcb, prw, prb; };
+inline TB tblock(const Plan& p, int l) {
+    const int b = p.p_blocks + l * P_PER_TBLOCK;
+    return TB{b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6, b + 7, b + 8, b + 9, b + 10, b + 11};
+}
+struct SB { int qkvw, qkvb, prw, prb, f1w, f1b, f2w, f2b; };
+inline SB sblock(const Plan& p, int l) {
+    const int b = p.p_blocks + l * (P_PER_SBLOCK + p.R * P_PER_SREPEAT);
+    return SB{b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6, b + 7};
+}
+struct SR { int n1w, n1b, n2w, n2b, cl, cw; };
+inline SR srepeat(const Plan& p, int l, int r) {
+    const int b = p.p_blocks + l * (P_PER_SBLOCK + p.R * P_PER_SREPEAT) + P_PER_SBLOCK + r * P_PER_SREPEAT;
+    return SR{b, b + 1, b + 2, b + 3, b + 4, b + 5};
+}
+}  // namespace
+
+extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* params, void* wcache, void* st) {
+    DCLIP_REQUIRE(e && params && wcache, "dclip_encoder_prepare: null argument");
+    const Plan& p = e->p;
+    bf16_t* W = (bf16_t*)wcache;
+    const int64_t D = p.D, F = p.F, E = p.E;
+    auto at = [&](int64_t off) -> void* { return off < 0 ? nullptr : (void*)(W + off); };
+    for (int l = 0; l < p.L; ++l) {
+        const auto& b = p.bw[l];
+        int iq, ip, i1, i2;
+        if (p.student) { SB s = sblock(p, l); iq = s.qkvw; ip = s.prw; i1 = s.f1w; i2 = s.f2w; }
+        else { TB t = tblock(p, l); iq = t.inw; ip = t.outw; i1 = t.fcw; i2 = t.prw; }
+        CK(dclip_cast_transpose_bf16(PF(params, iq), at(b.qkv), at(b.qkv_t), 3 * D, D, st));
+        CK(dclip_cast_transpose_bf16(PF(params, ip), at(b.proj), at(b.proj_t), D, D, st));
+        CK(dclip_cast_transpose_bf16(PF(params, i1), at(b.fc1), at(b.fc1_t), F, D, st));
+        CK(dclip_cast_transpose_bf16(PF(params, i2), at(b.fc2), at(b.fc2_t), D, F, st));
+    }
+    if (p.image) CK(dclip_cast_bf16(PF(params, 0), at(p.w_embed), D * p.K, st));                // conv weight [D, C*p*p]
+    else if (p.compressed) CK(dclip_cast_transpose_bf16(PF(params, 1), at(p.w_embed), at(p.w_embed_t), D, p.c.embed_rank, st));
+    if (p.student) CK(dclip_cast_transpose_bf16(PF(params, p.p_final + 2), at(p.w_head), at(p.w_head_t), E, D, st));
+    else CK(dclip_cast_transpose_bf16(PF(params, p.p_final + 2), nullptr, at(p.w_head), D, E, st));   // proj [D,E] -> [E,D]
+    return DCLIP_OK;
+}
+
+extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
+                                     const void* wcache, void* workspace, size_t ws_bytes, int training,
+                                     float* last_representation, void* st) {
+    DCLIP_REQUIRE(e && input && params && wcache && workspace && last_representation, "dclip_encoder_forward: null argument");
+    DCLIP_REQUIRE(B > 0, "dclip_encoder_forward: empty batch");
+    const Plan& p = e->p;
+    DCLIP_REQUIRE(!training || p.student, "dclip_encoder_forward: the teacher tower is inference-only");
+    Work w;
+    layout(p, B, training != 0, workspace, w);
+    DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    DCLIP_REQUIRE(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)wcache % 256) == 0, "dclip_encoder_forward: buffers must be 256-byte aligned");
+    const bf16_t* W = (const bf16_t*)wcache;
+    const int64_t N = p.N, D = p.D, F = p.F, E = p.E, M = B * N, H = p.H, hd = p.hd, Np = p.Np;
+    const float scale = 1.f / sqrtf((float)hd);
+    const int nex = p.L * p.R;
+
+    // ---- embedding -----------------------------------------------------------------------------------------
+    if (p.image) {
+        CK(dclip_im2row((const float*)input, w.patches, B, p.c.in_chans, p.c.resolution, p.c.patch, 1, st));
+        if (p.student) {   // params: 0 conv w, 1 conv b, 2 cls_token, 3 pos_embed
+            CK(dclip_token_table(PF(params, 3), PF(params, 2), PF(params, 1), w.tok_table, N, D, st));
+            CK(gemm(w.patches, p.K, W + p.w_embed, p.K, w.X[0], D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
+        } else {           // params: 0 conv1 w, 1 class_embedding, 2 positional_embedding, 3 ln_pre w, 4 ln_pre b
+            CK(dclip_token_table(PF(params, 2), PF(params, 1), nullptr, w.tok_table, N, D, st));
+            CK(gemm(w.patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
+            CK(dclip_layernorm_fwd(w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, 1, nullptr, nullptr, M, D, 1e-5f, st));
+        }
+    } else if (p.compressed) {   // params: 0 table [V,rank], 1 linear w [D,rank], 2 linear b, 3 pos
+        CK(dclip_embed_gather((const int64_t*)input, PF(params, 0), nullptr, w.patches, 0, M, N, p.c.embed_rank, st));
+        CK(dclip_token_table(PF(params, 3), nullptr, PF(params, 2), w.tok_table, N, D, st));
+        CK(gemm(w.patches, p.c.embed_rank, W + p.w_embed, p.c.embed_rank, w.X[0], D, M, D, p.c.embed_rank, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
+    } else {                     // params: 0 table [V,D], 1 pos [N,D]
+        CK(dclip_embed_gather((const int64_t*)input, PF(params, 0), PF(params, 1), w.X[0], 1, M, N, D, st));
+    }
+
+    // ---- blocks --------------------------------------------------------------------------------------------
+    for (int ei = 0; ei < nex; ++ei) {
+        const int l = ei / p.R, r = ei % p.R;
+        const auto& bw = p.bw[l];
+        ExecSave& s = w.ex[ei];
+        const float *n1w, *n1b, *n2w, *n2b, *bq, *bp, *b1, *b2, *wl = nullptr, *ww = nullptr;
+        if (p.student) {
+            SB sb = sblock(p, l); SR sr = srepeat(p, l, r);
+            n1w = PF(params, sr.n1w); n1b = PF(params, sr.n1b); n2w = PF(params, sr.n2w); n2b = PF(params, sr.n2b);
+            bq = PF(params, sb.qkvb); bp = PF(params, sb.prb); b1 = PF(params, sb.f1b); b2 = PF(params, sb.f2b);
+            if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
+        } else {
+            TB tb = tblock(p, l);
+            n1w = PF(params, tb.ln1w); n1b = PF(params, tb.ln1b); n2w = PF(params, tb.ln2w); n2b = PF(params, tb.ln2b);
+            bq = PF(params, tb.inb); bp = PF(params, tb.outb); b1 = PF(params, tb.fcb); b2 = PF(params, tb.prb);
+        }
+        float* xin = w.X[ei];
+        float* xout = w.X[ei + 1];
+        CK(dclip_layernorm_fwd(xin, D, nullptr, n1w, n1b, s.h1, D, 0, s.mean1, s.rstd1, M, D, 1e-5f, st));
+        CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
+        CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
+        CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+        CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
+        CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
+        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? DCLIP_ACT_GELU : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
+        CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
+    }
+
+    // ---- final norm + projection on the picked token only (class token / EOT = argmax of the ids) ----------------
+    CK(dclip_pick_index(p.image ? nullptr : (const int64_t*)input, w.pick, B, N, st));
+    const int f = p.p_final;
+    CK(dclip_layernorm_fwd(w.X[nex], D, w.pick, PF(params, f), PF(params, f + 1), w.hf, D, 0, w.meanf, w.rstdf, B, D, 1e-5f, st));
+    CK(gemm(w.hf, D, W + p.w_head, D, last_representation, E, B, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
+    return DCLIP_OK;
+}
+
+extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
+                                      void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                                      const float* d_last_representation, void* st) {
+    DCLIP_REQUIRE(e && input && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
+    const Plan& p = e->p;
+    DCLIP_REQUIRE(p.student, "dclip_encoder_backward: only the student tower trains");
+    Work w;
+    layout(p, B, true, workspace, w);
+    DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_backward: workspace too small");
+    const bf16_t* W = (const bf16_t*)wcache;
+    const int64_t N = p.N, D = p.D, F = p.F, E = p.E, M = B * N, H = p.H, hd = p.hd, Np = p.Np;
+    const float scale = 1.f / sqrtf((float)hd);
+    const int nex = p.L * p.R;
+    auto GR = [&](int i) -> float* { return (float*)grads[i]; };
+    hipStream_t hs = (hipStream_t)st;
+
+    if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(w.Gb, 0, (size_t)M * D * 2, hs) != hipSuccess) {
+        dclip_set_error("dclip_encoder_backward: memset failed");
+        return DCLIP_ELAUNCH;
+    }
+    // ---- head + final norm -----------------------------------------------------------------------------------
+    const int f = p.p_final;
+    CK(dclip_cast_bf16(d_last_representation, w.dout, B * E, st));
+    if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, st));
+    if (GR(f + 3)) CK(dclip_colsum_acc(w.dout, E, GR(f + 3), B, E, st));
+    CK(gemm(w.dout, E, W + p.w_head_t, E, w.dh, D, B, D, E, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, w.Gb, D, GR(f), GR(f + 1), B, D, st));
+
+    // ---- blocks, last execution first --------------------------------------------------------------------------
+    for (int ei = nex - 1; ei >= 0; --ei) {
+        const int l = ei / p.R, r = ei % p.R;
+        const auto& bw = p.bw[l];
+        const ExecSave& s = w.ex[ei];
+        const SB sb = sblock(p, l); const SR sr = srepeat(p, l, r);
+        const float *wl = nullptr, *ww = nullptr;
+        if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
+        // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+        if (GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.Gb, D, s.u, F, GR(sb.f2w), F, M, D, F, wsplits(M, D, F), st));
+        if (GR(sb.f2b)) CK(dclip_colsum_acc(w.Gb, D, GR(sb.f2b), M, D, st));
+        CK(gemm(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, nullptr, DCLIP_ACT_DGELU, s.z, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        if (GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s.h2, D, GR(sb.f1w), D, M, F, D, wsplits(M, F, D), st));
+        if (GR(sb.f1b)) CK(dclip_colsum_acc(w.dbig, F, GR(sb.f1b), M, F, st));
+        CK(gemm(w.dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, w.Gb, D, GR(sr.n2w), GR(sr.n2b), M, D, st));
+        // attention: x_mid = x_in + proj(attn(LN1(x_in)))
+        if (GR(sb.prw)) CK(dclip_gemm_tn_acc(w.Gb, D, s.ctx, D, GR(sb.prw), D, M, D, D, wsplits(M, D, D), st));
+        if (GR(sb.prb)) CK(dclip_colsum_acc(w.Gb, D, GR(sb.prb), M, D, st));
+        bf16_t* dctx = w.dh;
+        CK(gemm(w.Gb, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));                   // dR = dO V^T
+        CK(dclip_attn_tn(s.Rm, dctx, D, w.dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                       // dV = R^T dO
+        CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr, wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
+        CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, w.dqkv, 3 * D, B, H, N, Np, hd, scale, st));                    // dQ = dS K
+        CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, w.dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                    // dK = dS^T Q
+        if (GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s.h1, D, GR(sb.qkvw), D, M, 3 * D, D, wsplits(M, 3 * D, D), st));
+        if (params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), M, 3 * D, st));
+        CK(gemm(w.dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, w.Gb, D, GR(sr.n1w), GR(sr.n1b), M, D, st));
+    }
+
+    // ---- embedding ---------------------------------------------------------------------------------------------
+    if (hipMemsetAsync(w.tok_sum, 0, (size_t)N * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
+    if (p.image) {           // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
+        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), st));
+        if (GR(1) || GR(2) || GR(3)) {
+            CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
+            CK(dclip_token_table_bwd(w.tok_sum, GR(3), GR(2), GR(1), N, D, 1, st));
+        }
+    } else if (p.compressed) {   // grads: 0 table, 1 linear w, 2 linear b, 3 pos
+        const int64_t rk = p.c.embed_rank;
+        if (GR(1)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, rk, GR(1), rk, M, D, rk, wsplits(M, D, rk), st));
+        if (GR(2) || GR(3)) {
+            CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
+            CK(dclip_token_table_bwd(w.tok_sum, GR(3), nullptr, GR(2), N, D, 0, st));
+        }
+        if (GR(0)) {
+            CK(gemm(w.Gb, D, W + p.w_embed_t, D, w.demb, rk, M, rk, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
+            CK(dclip_embed_scatter_add((const int64_t*)input, w.demb, 1, GR(0), M, rk, st));
+        }
+    } else {                     // grads: 0 table, 1 pos
+        if (GR(0)) CK(dclip_embed_scatter_add((const int64_t*)input, w.G, 1, GR(0), M, D, st));
+        if (GR(1)) {
+            CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
+            CK(dclip_token_table_bwd(w.tok_sum, GR(1), nullptr, nullptr, N, D, 0, st));
+        }
+    }
+    return DCLIP_OK;
+}

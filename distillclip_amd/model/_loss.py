@@ -1,0 +1,115 @@
+"""LossCalculator (reference model/_loss.py:17-216) on the fused HIP loss kernel.
+
+Constructor arguments, percent / scale bookkeeping, error behaviour, `get_control_output()` and the returned
+`(loss, dict)` (dict holds the *scaled* terms, tower terms prefixed `image_` / `text_`) follow the reference.
+One `dclip_distill_loss` call computes every enabled term and d loss / d student embeddings; backward just scales them.
+"""
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from .component.output import ControlOutput
+from .. import ops
+
+IMAGE_TEXT_LOSS = ['hard_label', 'soft_label', 'logits_mse', 'fine_grain', 'cos_diff']     # reference _loss.py:14
+_TOWER_FUSED = ('out_l1', 'out_cos', 'out_kl', 'out_ce')
+_CROSS_FUSED = ('cos_diff', 'hard_label', 'soft_label', 'logits_mse')
+_KNOWN_UNSUPPORTED = ('embedding_mse', 'attention_score_mse', 'attention_probs_mse', 'hidden_rep_mse',
+                      'attention_probs_kl', 'last_value_map_kl', 'vit_kd', 'fine_grain', 'smd')
+_SLOT_TOWER = {'out_l1': 1, 'out_cos': 2, 'out_kl': 3, 'out_ce': 4}
+_SLOT_CROSS = {'cos_diff': 9, 'hard_label': 10, 'soft_label': 11, 'logits_mse': 12}
+
+
+class _FusedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s_img, s_txt, t_img, t_txt, weights, temperature):
+        two = s_txt is not None
+        scal, d_i, d_t = ops.distill_loss(s_img.detach().float().contiguous(), t_img.detach().float().contiguous(),
+                                          s_txt.detach().float().contiguous() if two else None,
+                                          t_txt.detach().float().contiguous() if two else None,
+                                          weights=weights, temperature=temperature)
+        ctx.save_for_backward(d_i, d_t if two else d_i)
+        ctx.two = two
+        ctx.mark_non_differentiable(scal)
+        return scal[0].clone(), scal
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scal):
+        d_i, d_t = ctx.saved_tensors
+        return d_i * g_loss, (d_t * g_loss) if ctx.two else None, None, None, None, None
+
+
+class LossCalculator(nn.Module):
+    def __init__(self, loss_name: List, loss_scale: dict = None, temperature=None, percent=None, smd_tau: float = 0.04,
+                 vit_kd_para: Dict = None):
+        super().__init__()
+        self.loss_name = loss_name
+        self.loss_scale = {}
+        if loss_scale is None:
+            loss_scale = {n: 1 for n in self.loss_name}
+        for n in loss_name:
+            self.loss_scale[n] = loss_scale.get(n, 1)                                   # reference :24-27
+        if percent is None:
+            percent = {n: 1 / len(loss_name) for n in self.loss_name}                   # :29-31
+        self.percent = percent
+        default_value = (1 - sum(self.percent.values())) / len(self.percent)
+        if len(loss_name) != len(self.percent.keys()) and default_value <= 0:
+            raise ValueError(f'there are some loss default percent is negative. Please check the sum of the percent {percent}'
+                             f'the default_value is {default_value} = (1 - sum(percent.values())) / len(percent)')
+        for n in loss_name:
+            if n not in self.percent:
+                self.percent[n] = default_value
+        assert abs(sum(self.percent.values()) - 1) <= 1e-5                              # :42
+        self.temperature = temperature
+        self.smd_tau = smd_tau
+        self.vit_kd_para = vit_kd_para
+        for n in loss_name:                                                             # :57-98
+            if n in _KNOWN_UNSUPPORTED:
+                raise NotImplementedError(f"loss '{n}' is registered by the reference but used by no shipped config; it is "
+                                          f'outside the HIP hot path (SURVEY.md §2.1)')
+            if n not in _TOWER_FUSED and n not in _CROSS_FUSED:
+                raise ValueError('Invalid Loss Type!')
+
+    def get_control_output(self):
+        return ControlOutput()      # reference :100-116: none of the fused terms needs extra activations
+
+    def set_percent(self, new_percent):
+        self.percent = new_percent
+
+    def set_scale(self, new_scale):
+        self.loss_scale = new_scale
+
+    def _weights(self, two_tower):
+        w = {}
+        for n in self.loss_name:
+            if n in _TOWER_FUSED or (two_tower and n in _CROSS_FUSED):
+                w[n] = self.loss_scale[n] * self.percent[n]
+        if 'out_kl' in w or 'soft_label' in w:
+            assert self.temperature, 'You should give the temperature for the kl loss'     # reference :133,:166
+        return w
+
+    def cal_tow_tower_loss(self, stu_out, tea_out):
+        loss, scal = _FusedLossFn.apply(stu_out.visual_output.last_representation, stu_out.text_output.last_representation,
+                                        tea_out.visual_output.last_representation, tea_out.text_output.last_representation,
+                                        self._weights(True), self.temperature)
+        res = {}
+        for prefix, off in (('image_', 0), ('text_', 4)):
+            for n in self.loss_name:
+                if n in _TOWER_FUSED:
+                    res[prefix + n] = scal[_SLOT_TOWER[n] + off] * self.loss_scale[n]
+        for n in self.loss_name:
+            if n in _CROSS_FUSED:
+                res[n] = scal[_SLOT_CROSS[n]] * self.loss_scale[n]
+        return loss, res
+
+    def cal_one_tower_loss(self, stu_out, tea_out):
+        loss, scal = _FusedLossFn.apply(stu_out.last_representation, None, tea_out.last_representation, None,
+                                        self._weights(False), self.temperature)
+        res = {n: scal[_SLOT_TOWER[n]] * self.loss_scale[n] for n in self.loss_name if n in _TOWER_FUSED}
+        return loss, res
+
+    def forward(self, stu_out, tea_out, model_type: str):
+        if model_type == 'all':
+            return self.cal_tow_tower_loss(stu_out, tea_out)
+        return self.cal_one_tower_loss(stu_out, tea_out)

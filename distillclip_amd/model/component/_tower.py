@@ -1,0 +1,178 @@
+"""HipTower: binds an nn.Module's parameters to one dclip_encoder handle (include/dclip.h, tower-level runtime).
+
+Owns the flat f32 parameter / gradient buffers (parameters become views of one buffer so the optimizer and the
+RCCL gradient exchange see a single contiguous tensor), the bf16 weight cache and the activation workspace.
+"""
+import ctypes
+
+import torch
+
+from ..._lib import lib
+
+
+class EncoderCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'kind', 'modality', 'tokens', 'width', 'heads', 'layers', 'repeats', 'mlp_dim', 'out_dim', 'patch', 'resolution',
+        'in_chans', 'vocab', 'embed_rank', 'head_mix', 'causal')]
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class HipTower:
+    def __init__(self, module, cfg: EncoderCfg, param_names):
+        """param_names: reference state_dict keys in the canonical order of include/dclip.h (None = absent)."""
+        self.module = module
+        self.cfg = cfg
+        self.param_names = list(param_names)
+        self._handle = lib().dclip_encoder_create(ctypes.byref(cfg))
+        if not self._handle:
+            raise ValueError(lib().dclip_last_error_string().decode())
+        n = lib().dclip_encoder_num_params(self._handle)
+        if n != len(self.param_names):
+            raise RuntimeError(f'parameter table mismatch: runtime expects {n}, module lists {len(self.param_names)}')
+        self.flat = None
+        self.flat_grad = None
+        self.wcache = None
+        self.wcache_dirty = True
+        self.workspace = None
+        self._ws_key = None
+        self._saved_batch = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_handle', None):
+                lib().dclip_encoder_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ---- parameter plumbing -------------------------------------------------------------------------------------
+    def _params(self):
+        table = dict(self.module.named_parameters())
+        return [None if n is None else table[n] for n in self.param_names]
+
+    def materialize(self, device):
+        """(Re)build the flat buffers when the parameters are not (any more) views of them (first use, .to(), .cuda())."""
+        ps = self._params()
+        live = [p for p in ps if p is not None]
+        ok = self.flat is not None and self.flat.device == device
+        if ok:
+            off = 0
+            for p in live:
+                if p.data_ptr() != self.flat.data_ptr() + off * 4 or p.dtype != torch.float32:
+                    ok = False
+                    break
+                off += (p.numel() + 63) // 64 * 64
+        if ok:
+            return
+        if device.type != 'cuda':
+            raise RuntimeError('distillclip_amd towers run on MI355X only (no CPU fallback): move the module and its inputs to cuda')
+        total = sum((p.numel() + 63) // 64 * 64 for p in live)
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        with torch.no_grad():
+            for p in live:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = None
+                off += (n + 63) // 64 * 64
+        self.flat, self.flat_grad = flat, flat_grad
+        self._offsets = []
+        off = 0
+        for p in live:
+            self._offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        wbytes = lib().dclip_encoder_wcache_bytes(self._handle)
+        self.wcache = torch.empty(wbytes, dtype=torch.uint8, device=device)
+        self.wcache_dirty = True
+
+    def attach_grads(self):
+        """Make p.grad views of the flat gradient buffer.  If any trainable p.grad was dropped (zero_grad(set_to_none)),
+        the buffer is zeroed first — the kernels accumulate with +=, like autograd does into an existing .grad."""
+        live = [p for p in self._params() if p is not None]
+        fresh = any(p.requires_grad and p.grad is None for p in live)
+        if fresh:
+            self.flat_grad.zero_()
+        for p, off in zip(live, self._offsets):
+            if p.requires_grad:
+                want = self.flat_grad.data_ptr() + off * 4
+                if p.grad is None or p.grad.data_ptr() != want:
+                    p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    def _ensure_workspace(self, batch, training, device):
+        key = (batch, bool(training))
+        need = lib().dclip_encoder_workspace_bytes(self._handle, batch, 1 if training else 0)
+        if self.workspace is None or self.workspace.numel() < need or self.workspace.device != device:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        self._ws_key = key
+
+    def prepare(self):
+        ps = self._params()
+        lib().dclip_encoder_prepare(self._handle, _ptr_array(ps), self.wcache.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        self.wcache_dirty = False
+
+    # ---- execution -----------------------------------------------------------------------------------------------
+    def forward(self, x, training):
+        if not x.is_cuda:
+            raise RuntimeError('distillclip_amd towers need CUDA(HIP) inputs; there is no CPU fallback')
+        expect = torch.float32 if self.cfg.modality == 0 else torch.int64
+        if x.dtype != expect:
+            x = x.to(expect)
+        x = x.contiguous()
+        self.materialize(x.device)
+        B = x.shape[0]
+        if training or self.wcache_dirty or any(p.requires_grad for p in self.module.parameters()):
+            self.prepare()      # trainable towers: the optimizer moved the f32 masters since the last cast
+        self._ensure_workspace(B, training, x.device)
+        out = torch.empty((B, self.cfg.out_dim), dtype=torch.float32, device=x.device)
+        ps = self._params()
+        lib().dclip_encoder_forward(self._handle, x.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
+                                    self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
+                                    out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self._saved_batch = B if training else None
+        return out, x
+
+    def backward(self, x, d_out):
+        B = x.shape[0]
+        if self._saved_batch != B:
+            raise RuntimeError('backward without a matching training-mode forward (activations are kept in the workspace '
+                               'of the most recent forward)')
+        self.attach_grads()
+        ps = self._params()
+        gs = [None if (p is None or not p.requires_grad) else p.grad for p in ps]
+        d_out = d_out.contiguous().float()
+        lib().dclip_encoder_backward(self._handle, x.data_ptr(), B, _ptr_array(ps), _ptr_array(gs), self.wcache.data_ptr(),
+                                     self.workspace.data_ptr(), self.workspace.numel(), d_out.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        self._saved_batch = None
+
+
+class _TowerFn(torch.autograd.Function):
+    """autograd edge of a student tower: forward / backward are one C-ABI call each."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, tower):
+        out, xin = tower.forward(x, training=True)
+        ctx.tower = tower
+        ctx.x = xin
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ctx.tower.backward(ctx.x, d_out)
+        return None, None, None
+
+
+def run_tower(tower, x, anchor):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in tower.module.parameters()):
+        return _TowerFn.apply(anchor, x, tower)
+    out, _ = tower.forward(x, training=False)
+    return out

@@ -1,0 +1,129 @@
+"""Frozen CLIP image teacher (reference model/component/image_encoder.py:8-65 wrapping _common.py:170-221).
+
+Parameters live under `visual.` with the OpenAI-CLIP key names so teacher archives load by key (reference
+model/utils.py:140-144).  Inference only: the plain-`ImageEncoder`-as-student role (is_student=True) is not used by any
+shipped config and is not implemented.
+"""
+import torch
+from torch import nn
+
+from .output import ControlOutput, VisionTransformerOutput
+from ._tower import EncoderCfg, HipTower, run_tower
+
+
+class _LN(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Lin(nn.Module):
+    def __init__(self, fan_in, fan_out, std):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(fan_out, fan_in) * std)
+        self.bias = nn.Parameter(torch.zeros(fan_out))
+
+
+class _MHA(nn.Module):
+    def __init__(self, width, attn_std, proj_std):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.randn(3 * width, width) * attn_std)
+        self.in_proj_bias = nn.Parameter(torch.randn(3 * width) * attn_std)
+        self.out_proj = _Lin(width, width, proj_std)
+
+
+class _MLP(nn.Module):
+    def __init__(self, width, fc_std, proj_std):
+        super().__init__()
+        self.c_fc = _Lin(width, 4 * width, fc_std)
+        self.c_proj = _Lin(4 * width, width, proj_std)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, width, layers):
+        super().__init__()
+        # init stds of reference image_encoder.py:40-48 / text_encoder.py:98-106
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        self.attn = _MHA(width, width ** -0.5, proj_std)
+        self.ln_1 = _LN(width)
+        self.mlp = _MLP(width, (2 * width) ** -0.5, proj_std)
+        self.ln_2 = _LN(width)
+
+
+class TeacherTransformer(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.Sequential(*[_ResBlock(width, layers) for _ in range(layers)])
+
+
+def teacher_block_names(prefix, layers):
+    out = []
+    for i in range(layers):
+        p = f'{prefix}transformer.resblocks.{i}.'
+        out += [p + 'ln_1.weight', p + 'ln_1.bias', p + 'attn.in_proj_weight', p + 'attn.in_proj_bias',
+                p + 'attn.out_proj.weight', p + 'attn.out_proj.bias', p + 'ln_2.weight', p + 'ln_2.bias',
+                p + 'mlp.c_fc.weight', p + 'mlp.c_fc.bias', p + 'mlp.c_proj.weight', p + 'mlp.c_proj.bias']
+    return out
+
+
+class _Visual(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
+        super().__init__()
+        self.input_resolution, self.output_dim = input_resolution, output_dim
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)    # parameters only
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(torch.randn(width) * 0.02)
+        self.positional_embedding = nn.Parameter(torch.randn((input_resolution // patch_size) ** 2 + 1, width) * 0.01)
+        self.ln_pre = _LN(width)
+        self.transformer = TeacherTransformer(width, layers, heads)
+        self.ln_post = _LN(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+
+class ImageEncoder(nn.Module):
+    def __init__(self, is_student, vit_paras, tea_transformer_width=None):
+        super().__init__()
+        if is_student:
+            raise NotImplementedError('ImageEncoder(is_student=True) (a plain CLIP ViT as student) is not used by any shipped '
+                                      'config; students are RepeatVisionTransformer (SURVEY.md §2 row 6)')
+        vit_paras = dict(vit_paras)
+        self.layers = vit_paras['layers']
+        if vit_paras.get('need_layers') is None:
+            vit_paras['need_layers'] = tuple(range(self.layers))
+        self.vit_paras = vit_paras
+        self.is_student = False
+        self.visual = _Visual(vit_paras['input_resolution'], vit_paras['patch_size'], vit_paras['width'],
+                              vit_paras['layers'], vit_paras['heads'], vit_paras['output_dim'])
+        w, res, patch = vit_paras['width'], vit_paras['input_resolution'], vit_paras['patch_size']
+        cfg = EncoderCfg(kind=0, modality=0, tokens=(res // patch) ** 2 + 1, width=w, heads=vit_paras['heads'],
+                         layers=self.layers, repeats=1, mlp_dim=4 * w, out_dim=vit_paras['output_dim'], patch=patch,
+                         resolution=res, in_chans=3, vocab=0, embed_rank=0, head_mix=0, causal=0)
+        names = ['visual.conv1.weight', 'visual.class_embedding', 'visual.positional_embedding', 'visual.ln_pre.weight',
+                 'visual.ln_pre.bias'] + teacher_block_names('visual.', self.layers) + \
+                ['visual.ln_post.weight', 'visual.ln_post.bias', 'visual.proj']
+        object.__setattr__(self, '_tower', HipTower(self, cfg, names))
+        self.register_load_state_dict_post_hook(lambda m, keys: setattr(m._tower, 'wcache_dirty', True))
+
+    @property
+    def need_layers(self):
+        return self.vit_paras['need_layers']
+
+    @property
+    def output_layer(self):
+        return self.visual.proj
+
+    def encode_image(self, image, control_output: ControlOutput = None):
+        co = control_output
+        if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map or co.need_rep or co.need_emb):
+            raise NotImplementedError('teacher hidden states / attention maps are not exported by the HIP tower yet')
+        with torch.no_grad():
+            out, _ = self._tower.forward(image, training=False)
+        return VisionTransformerOutput(last_representation=out)
+
+    def forward(self, image, control_output: ControlOutput = None):
+        return self.encode_image(image, control_output)
+
+    def hyper_para(self):
+        return self.vit_paras

@@ -1,0 +1,57 @@
+"""Frozen CLIP text teacher (reference model/component/text_encoder.py:8-92): token + positional embedding, causal
+residual-attention blocks, ln_final, text_projection, EOT pooling by argmax of the token ids."""
+import torch
+from torch import nn
+
+from .output import ControlOutput, TextTransformerOutput
+from ._tower import EncoderCfg, HipTower
+from .image_encoder import TeacherTransformer, _LN, teacher_block_names
+
+
+class TextEncoder(nn.Module):
+    def __init__(self, transformer_width, transformer_layers, transformer_heads, context_length, need_layers, vocab_size,
+                 embed_dim, tea_transformer_width=None, is_student=True, drop_out=0., compression_embedding=False,
+                 embedding_compression_dim=256):
+        super().__init__()
+        if is_student or compression_embedding:
+            raise NotImplementedError('TextEncoder as a student (is_student=True / compression_embedding) is not used by any '
+                                      'shipped config; students are RepeatTextTransformer (SURVEY.md §2 row 6)')
+        if drop_out:
+            raise NotImplementedError('dropout is 0 for the frozen teacher')
+        self.context_length, self.transformer_width, self.transformer_heads = context_length, transformer_width, transformer_heads
+        self.vocab_size, self.embed_dim, self.layers = vocab_size, embed_dim, transformer_layers
+        self.is_student = False
+        self._need_layers = need_layers
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        self.positional_embedding = nn.Parameter(torch.randn(context_length, transformer_width) * 0.01)
+        self.ln_final = _LN(transformer_width)
+        self.text_projection = nn.Parameter(torch.randn(transformer_width, embed_dim) * transformer_width ** -0.5)
+        self.transformer = TeacherTransformer(transformer_width, transformer_layers, transformer_heads)
+        cfg = EncoderCfg(kind=0, modality=1, tokens=context_length, width=transformer_width, heads=transformer_heads,
+                         layers=transformer_layers, repeats=1, mlp_dim=4 * transformer_width, out_dim=embed_dim, patch=0,
+                         resolution=0, in_chans=0, vocab=vocab_size, embed_rank=0, head_mix=0, causal=1)
+        names = ['token_embedding.weight', 'positional_embedding'] + teacher_block_names('', transformer_layers) + \
+                ['ln_final.weight', 'ln_final.bias', 'text_projection']
+        object.__setattr__(self, '_tower', HipTower(self, cfg, names))
+        self.register_load_state_dict_post_hook(lambda m, keys: setattr(m._tower, 'wcache_dirty', True))
+
+    @property
+    def need_layers(self):
+        return self._need_layers
+
+    def encode_text(self, text, control_output: ControlOutput = None):
+        co = control_output
+        if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map or co.need_rep or co.need_emb):
+            raise NotImplementedError('teacher hidden states / attention maps are not exported by the HIP tower yet')
+        with torch.no_grad():
+            out, _ = self._tower.forward(text, training=False)
+        return TextTransformerOutput(last_representation=out)
+
+    def forward(self, text, control_output: ControlOutput = None):
+        return self.encode_text(text, control_output)
+
+    def hyper_para(self):
+        return {'context_length': self.context_length, 'transformer_width': self.transformer_width,
+                'transformer_layers': self.layers, 'transformer_heads': self.transformer_heads,
+                'vocab_size': self.vocab_size, 'embed_dim': self.embed_dim}

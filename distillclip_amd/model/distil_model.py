@@ -1,0 +1,108 @@
+"""DistillModel (reference model/distil_model.py:19-221): one-tower distillation.
+
+The reference class is a pytorch_lightning.LightningModule; Lightning is not installed here, so the same constructor,
+`forward`, `training_step`, `configure_optimizers`, `freeze_image_embedding` are provided on a plain nn.Module (the
+methods Lightning would call).  Logging / wandb / torchmetrics validation are out of scope.
+"""
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from ._loss import LossCalculator
+from .utils import teacher_load
+from .component.weight_share_model import RepeatVisionTransformer
+from ..optim import FusedAdamW, EpochCosineSchedule
+from ..parallel import GradSync
+
+
+class _HParams(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class DistillModel(nn.Module):
+    def __init__(self, student_encoder: torch.nn.Module, loss_control_para: Dict, download_root: str,
+                 teacher_name: str = 'ViT-B/32', freeze_embed: bool = False, teacher_need_layers: List = None,
+                 model_type: str = 'image', warm_steps=10, total_steps=200, weight_decay=1e-3, lr: float = 1e-3,
+                 norm: bool = False, unfreeze_epoch=None, teacher_state_dict=None):
+        super().__init__()
+        if model_type not in ['text', 'image']:
+            raise ValueError(f"the model_type should in ['text', 'image'], bug got {model_type}")     # reference :44-45
+        self.hparams = _HParams(loss_control_para=loss_control_para, download_root=download_root, teacher_name=teacher_name,
+                                freeze_embed=freeze_embed, teacher_need_layers=teacher_need_layers, model_type=model_type,
+                                warm_steps=warm_steps, total_steps=total_steps, weight_decay=weight_decay, lr=lr, norm=norm,
+                                unfreeze_epoch=unfreeze_epoch)
+        self.student = student_encoder
+        self.teacher_name = teacher_name
+        self.teacher = teacher_load(teacher_name, download_root, model_type, need_layers=teacher_need_layers,
+                                    state_dict=teacher_state_dict)
+        self.loss_control = LossCalculator(**loss_control_para)
+        self.need_return_para = self.loss_control.get_control_output()
+        for p in self.teacher.parameters():
+            p.requires_grad = False                                                       # reference :59-60
+        if model_type == 'image' and freeze_embed:
+            self.freeze_image_embedding()
+        self.k_list = [1, 3, 5, 10, 20, 50]
+        self.current_epoch = 0
+        self._sync = None
+
+    def forward(self, inputs):
+        # reference :81-89
+        student_outs = self.student(inputs, self.need_return_para)
+        with torch.no_grad():
+            teacher_outs = self.teacher(inputs, self.need_return_para)
+        if self.hparams.norm:
+            raise NotImplementedError('norm=True (pre-normalised representations) is False in every shipped config')
+        return student_outs, teacher_outs
+
+    def training_step(self, inputs, batch_idx=0):
+        # reference :97-102 (logging left to the caller: cal_res holds every scalar self.log would receive)
+        self.teacher.eval()
+        student_outs, teacher_outs = self.forward(inputs)
+        loss, cal_res = self.loss_control(student_outs, teacher_outs, self.hparams.model_type)
+        self.last_cal_res = cal_res
+        return loss
+
+    def backward_and_sync(self, loss):
+        """loss.backward() + the DDP gradient average of the reference's strategy (ddp_find_unused_parameters_false)."""
+        loss.backward()
+        if self._sync is None:
+            self._sync = GradSync()
+        self._sync.launch(self.student._tower.flat_grad)
+        self._sync.wait()
+
+    def configure_optimizers(self):
+        # reference :160-169: AdamW over every requires_grad parameter (one group) + cosine schedule stepped per epoch
+        self.student._tower.materialize(next(self.student.parameters()).device)
+        opt = FusedAdamW([self.student._tower], lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
+        sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
+        return [opt], [sched]
+
+    def on_train_epoch_start(self):
+        if self.hparams.unfreeze_epoch and self.current_epoch >= self.hparams.unfreeze_epoch:
+            self.unfreeze_embed()
+            self.hparams.unfreeze_epoch = False
+
+    def unfreeze_embed(self):
+        for _, p in self.student.named_parameters():
+            p.requires_grad = True
+
+    def freeze_image_embedding(self):
+        # reference :197-213
+        if not isinstance(self.student, RepeatVisionTransformer):
+            raise NotImplementedError('freeze_embed is implemented for RepeatVisionTransformer students')
+        stu_keys = ['patch_embed.proj.weight', 'cls_token', 'pos_embed']
+        tea_keys = ['visual.conv1.weight', 'visual.class_embedding', 'visual.positional_embedding']
+        sw, tw = self.student.state_dict(), self.teacher.state_dict()
+        for s_k, t_k in zip(stu_keys, tea_keys):
+            w = tw[t_k]
+            if 'cls_token' in s_k:
+                w = w.unsqueeze(0).unsqueeze(0)
+            if 'pos_embed' in s_k:
+                w = w.unsqueeze(0)
+            sw[s_k] = w
+        self.student.load_state_dict(sw)
+        for n, p in self.student.named_parameters():
+            if n in stu_keys:
+                p.requires_grad = False

@@ -1,0 +1,138 @@
+"""DualDistillModel (reference model/dual_distill_model.py:41-268): two-tower (image + text) distillation.
+
+Same constructor / forward / training_step / configure_optimizers / load_weight / freeze_with_prefix as the reference's
+LightningModule, on a plain nn.Module (Lightning, wandb and torchmetrics are absent here; validation metrics are the
+"next" row N3 of SURVEY.md §8f).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ._loss import LossCalculator
+from .utils import teacher_load
+from .component.clip_model import CLIPModel
+from .component.output import CLIPOutput
+from .component.weight_share_model import RepeatVisionTransformer
+from .distil_model import _HParams
+from ..optim import FusedAdamW, EpochCosineSchedule
+from ..parallel import GradSync
+
+
+def load_weight(image_student, text_student, load_path):
+    # reference dual_distill_model.py:22-38: Lightning checkpoint -> strip the 'student.' prefix
+    def load_one_model(model: nn.Module, cpk: Optional[str]):
+        if cpk is None:
+            raise ValueError('the cpk is None! if you set the load_path parameter in model,'
+                             ' you should give the image and text checkpoint path')
+        save_res = torch.load(cpk, map_location='cpu')
+        state_dict = {k.replace('student.', ''): v for k, v in save_res['state_dict'].items() if k.startswith('student')}
+        model.load_state_dict(state_dict)
+        return model
+
+    return load_one_model(image_student, load_path['image']), load_one_model(text_student, load_path['text'])
+
+
+class DualDistillModel(nn.Module):
+    def __init__(self, image_student: nn.Module, text_student: nn.Module, loss_control_para: Dict, warm_steps, total_steps,
+                 weight_decay, lr: float, download_root: str, norm=False, teacher_name: str = 'ViT-B/32',
+                 freeze_embed: bool = False, unfreeze_epoch: int = None, load_path: Dict = None,
+                 teacher_need_layers: List = None, freeze_prefix: List = None, teacher_state_dict=None):
+        super().__init__()
+        self.hparams = _HParams(loss_control_para=loss_control_para, warm_steps=warm_steps, total_steps=total_steps,
+                                weight_decay=weight_decay, lr=lr, download_root=download_root, norm=norm,
+                                teacher_name=teacher_name, freeze_embed=freeze_embed, unfreeze_epoch=unfreeze_epoch,
+                                load_path=load_path, teacher_need_layers=teacher_need_layers, freeze_prefix=freeze_prefix)
+        if load_path:
+            image_student, text_student = load_weight(image_student, text_student, load_path)
+        self.student = CLIPModel(True, image_student, text_student, norm)
+        self.teacher = teacher_load(teacher_name, download_root, 'all', need_layers=teacher_need_layers,
+                                    state_dict=teacher_state_dict)
+        for p in self.teacher.parameters():
+            p.requires_grad = False                                                       # reference :76-77
+        self.loss_control = LossCalculator(**loss_control_para)
+        self.need_return_para = self.loss_control.get_control_output()
+        if freeze_embed:
+            self.freeze_image_embedding()
+        self.unfreeze_epoch = unfreeze_epoch
+        self.freeze_with_prefix(prefix_list=freeze_prefix)
+        self.k_list = [1, 3, 5, 10, 20, 50]
+        self.current_epoch = 0
+        self._sync = None
+
+    def towers(self):
+        return [self.student.image_encoder._tower, self.student.text_encoder._tower]
+
+    def forward(self, inputs) -> Tuple[CLIPOutput, CLIPOutput]:
+        # reference :106-112.  The batch is (image, text) while CLIPModel.forward takes (text, image).
+        image, text = inputs
+        student_outs = self.student(text, image, self.need_return_para)
+        with torch.no_grad():      # the reference only relies on requires_grad=False; values are identical
+            teacher_outs = self.teacher(text, image, self.need_return_para)
+        if self.hparams.norm:
+            raise NotImplementedError('norm=True (pre-normalised representations) is False in every shipped config')
+        return student_outs, teacher_outs
+
+    def training_step(self, inputs, batch_idx=0):
+        # reference :120-127
+        self.teacher.eval()
+        student_outs, teacher_outs = self.forward(inputs)
+        loss, cal_res = self.loss_control(student_outs, teacher_outs, 'all')
+        self.last_cal_res = cal_res
+        return loss
+
+    def backward_and_sync(self, loss):
+        """loss.backward() + DDP gradient averaging (reference strategy ddp_find_unused_parameters_false, l_clip.yaml:56).
+        Each tower's flat gradient buffer is exchanged on a side stream right after its backward has been enqueued."""
+        loss.backward()
+        if self._sync is None:
+            self._sync = GradSync()
+        for tw in self.towers():
+            self._sync.launch(tw.flat_grad)
+        self._sync.wait()
+
+    def configure_optimizers(self):
+        # reference :194-202
+        dev = next(self.student.parameters()).device
+        for tw in self.towers():
+            tw.materialize(dev)
+        opt = FusedAdamW(self.towers(), lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
+        sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
+        return [opt], [sched]
+
+    def on_train_epoch_start(self):
+        if self.unfreeze_epoch and self.current_epoch >= self.unfreeze_epoch:
+            self.unfreeze_embed()
+            self.unfreeze_epoch = False
+
+    def freeze_with_prefix(self, prefix_list):
+        # reference :230-238
+        if prefix_list is None:
+            return
+        for n, p in self.student.named_parameters():
+            if any(n.startswith(prefix) for prefix in prefix_list):
+                p.requires_grad = False
+
+    def unfreeze_embed(self):
+        for _, p in self.student.named_parameters():
+            p.requires_grad = True
+
+    def freeze_image_embedding(self):
+        # reference :240-268: teacher patch / class / positional embeddings copied into the image student and frozen
+        enc = self.student.image_encoder
+        if not isinstance(enc, RepeatVisionTransformer):
+            raise NotImplementedError('freeze_embed is implemented for RepeatVisionTransformer students')
+        keys = {'patch_embed.proj.weight': 'image_encoder.visual.conv1.weight',
+                'cls_token': 'image_encoder.visual.class_embedding', 'pos_embed': 'image_encoder.visual.positional_embedding'}
+        sw, tw = enc.state_dict(), self.teacher.state_dict()
+        for s_k, t_k in keys.items():
+            w = tw[t_k]
+            if s_k == 'cls_token':
+                w = w.unsqueeze(0).unsqueeze(0)
+            if s_k == 'pos_embed':
+                w = w.unsqueeze(0)
+            sw[s_k] = w
+        enc.load_state_dict(sw)
+        for n, p in enc.named_parameters():
+            if n in keys:
+                p.requires_grad = False

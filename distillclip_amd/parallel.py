@@ -1,0 +1,42 @@
+"""Data-parallel gradient exchange over RCCL (torch.distributed backend "nccl" on ROCm), one process per GPU.
+
+Reference behaviour: Lightning DDP all-reduces the student's f32 gradients.  Here every tower
+already keeps its gradients in ONE flat f32 buffer, so the exchange is a handful of large collectives issued on a
+side HIP stream; the image tower's exchange overlaps the text tower's backward (and vice versa) by construction of
+`GradSync.launch(tower)` being called as soon as a tower's backward call has been enqueued.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, bucket_elems=32 * 1024 * 1024):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.bucket = bucket_elems
+        self._stream = None
+        self._pending = []
+
+    def launch(self, flat_grad):
+        """average `flat_grad` across ranks, asynchronously with respect to the compute stream."""
+        if not self.enabled or flat_grad is None:
+            return
+        if flat_grad.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                for b in range(0, flat_grad.numel(), self.bucket):
+                    chunk = flat_grad[b:b + self.bucket]
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG)      # RCCL averages in the collective itself
+            self._pending.append(flat_grad)
+        else:   # gloo / CPU rehearsal of the same call pattern
+            for b in range(0, flat_grad.numel(), self.bucket):
+                chunk = flat_grad[b:b + self.bucket]
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+                chunk.mul_(1.0 / self.world)
+
+    def wait(self):
+        if self._stream is not None and self._pending:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._pending = []

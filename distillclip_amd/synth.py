@@ -143,7 +143,7 @@ def _student_blocks(seed, sd, prefix, dim, n_blocks, heads, repeats, mlp_ratio, 
                 for c in ('conv_l', 'conv_w'):
                     k = p + f'attn.{c}.instances.{r}.weight'
                     sd[k] = (eye + normal(seed, k, (heads, heads), 0.3 * heads ** -0.5)).reshape(heads, heads, 1, 1)
-        sd[p + 'attn.qkv.weight'] = normal(seed, p + 'attn.qkv.weight', (3 * dim, dim), 2.0 * dim ** -0.5)
+        sd[p + 'attn.qkv.weight'] = normal(seed, p + 'attn.qkv.weight', (3 * dim, dim), dim ** -0.5)
         if qkv_bias:
             sd[p + 'attn.qkv.bias'] = normal(seed, p + 'attn.qkv.bias', (3 * dim,), 0.02)
         sd[p + 'attn.proj.weight'] = normal(seed, p + 'attn.proj.weight', (dim, dim), dim ** -0.5)

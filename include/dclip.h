@@ -151,6 +151,64 @@ int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_tx
  *   loss_acc[0] += coef * mean((s - t)^2) ; ds_acc (nullable) += coef * 2 (s - t) / n */
 int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, float* loss_acc, float* ds_acc, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Tower-level runtime: one call issues the whole launch sequence of an encoder tower on `stream`.
+ *   teacher: reference model/component/_common.py:188-221 (VisionTransformer.forward) and
+ *            model/component/text_encoder.py:62-92 (TextEncoder.encode_text) — inference only;
+ *   student: reference model/component/weight_share_model.py:336-372 / :482-512 (forward_features) and autograd of it.
+ * The handle is an immutable host-side plan; params / grads / wcache / workspace are caller-owned device buffers.
+ *
+ * Canonical parameter order (arrays of f32 device pointers; names are the reference's state_dict keys):
+ *  teacher image : visual.conv1.weight, visual.class_embedding, visual.positional_embedding, visual.ln_pre.{weight,bias},
+ *                  per layer i { ln_1.weight, ln_1.bias, attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight,
+ *                  attn.out_proj.bias, ln_2.weight, ln_2.bias, mlp.c_fc.weight, mlp.c_fc.bias, mlp.c_proj.weight,
+ *                  mlp.c_proj.bias }, visual.ln_post.{weight,bias}, visual.proj
+ *  teacher text  : token_embedding.weight, positional_embedding, per layer i { same 12 }, ln_final.{weight,bias},
+ *                  text_projection
+ *  student image : patch_embed.proj.weight, patch_embed.proj.bias, cls_token, pos_embed,
+ *                  per block i { attn.qkv.weight, attn.qkv.bias (NULL if absent), attn.proj.weight, attn.proj.bias,
+ *                  mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, per repeat r { norm1.instances.r.weight,
+ *                  .bias, norm2.instances.r.weight, .bias, attn.conv_l.instances.r.weight, attn.conv_w.instances.r.weight
+ *                  (NULL, NULL when head_mix = 0) } }, norm.weight, norm.bias, head.weight, head.bias
+ *  student text  : patch_embed.weight, pos_embed   (embed_rank = 0)   or
+ *                  patch_embed.0.weight, patch_embed.1.weight, patch_embed.1.bias, pos_embed   (embed_rank > 0),
+ *                  then blocks / norm / head as above.
+ * `grads` uses the same order; a NULL entry means "frozen, skip" (requires_grad = False).  Gradients ACCUMULATE (+=).
+ */
+typedef struct dclip_encoder_cfg {
+    int32_t kind;        /* 0 teacher (CLIP residual blocks, QuickGELU), 1 student (weight-shared MiniViT blocks, erf GELU) */
+    int32_t modality;    /* 0 image, 1 text */
+    int32_t tokens;      /* N: (resolution / patch)^2 + 1 for images, context_length for text */
+    int32_t width;       /* D */
+    int32_t heads;       /* H (D / H in {32, 64}) */
+    int32_t layers;      /* distinct blocks: teacher = transformer layers, student = depth / repeated_times */
+    int32_t repeats;     /* repeated_times (teacher: 1) */
+    int32_t mlp_dim;     /* int(D * mlp_ratio) */
+    int32_t out_dim;     /* E */
+    int32_t patch, resolution, in_chans;  /* image only */
+    int32_t vocab, embed_rank;            /* text only; embed_rank = embedding_compression_dim or 0 */
+    int32_t head_mix;    /* use_transform: conv_l / conv_w cross-head mixing */
+    int32_t causal;      /* teacher text: 1 */
+} dclip_encoder_cfg;
+
+typedef struct dclip_encoder dclip_encoder;
+
+dclip_encoder* dclip_encoder_create(const dclip_encoder_cfg* cfg);   /* NULL + last_error_string on a bad configuration */
+void dclip_encoder_destroy(dclip_encoder* enc);
+int64_t dclip_encoder_num_params(const dclip_encoder* enc);
+size_t dclip_encoder_wcache_bytes(const dclip_encoder* enc);
+size_t dclip_encoder_workspace_bytes(const dclip_encoder* enc, int64_t B, int training);
+/* refresh the bf16 GEMM-weight cache from the f32 parameters (student: every step; teacher: once) */
+int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, void* wcache, void* stream);
+/* input: image f32 [B,C,res,res] or token ids i64 [B,N].  last_representation: f32 [B,E] (class token / EOT row).
+ * training = 1 keeps every activation backward needs inside `workspace` (student only). */
+int dclip_encoder_forward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
+                          const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
+                          void* stream);
+int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
+                           void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                           const float* d_last_representation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
