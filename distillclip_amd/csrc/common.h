@@ -25,6 +25,20 @@ void dclip_set_error(const char* fmt, ...);
         }                                         \
     } while (0)
 
+// launch trace (capi.cpp): open() returns false unless dclip_trace_begin() enabled tracing
+bool dclip_trace_open(int kind, double flops, double bytes, void* stream, int* slot);
+void dclip_trace_close(int slot, void* stream);
+struct TraceScope {
+    int slot = -1; void* st;
+    TraceScope(int kind, double flops, double bytes, void* stream) : st(stream) { if (!dclip_trace_open(kind, flops, bytes, stream, &slot)) slot = -1; }
+    ~TraceScope() { if (slot >= 0) dclip_trace_close(slot, st); }
+};
+#define DCLIP_TRACE_GEMM_NT 0
+#define DCLIP_TRACE_GEMM_TN 1
+#define DCLIP_TRACE_LAYERNORM 2
+#define DCLIP_TRACE_LOSS 3
+#define DCLIP_TRACE_ATTN 4
+
 static inline int dclip_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -312,6 +312,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.row_group = (int)row_group; p.rowadd = rowadd;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     hipStream_t st = (hipStream_t)stream;
+    TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
+                  2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream);
     switch (act) {
         case 0: return launch_nt<0>(p, out_f32 != 0, st);
         case 1: return launch_nt<1>(p, out_f32 != 0, st);
@@ -337,6 +339,7 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     p.chunk = chunk;
     p.splits = (int)((M + chunk - 1) / chunk);
     const int grid = p.tiles_p * p.tiles_q * p.splits;
+    TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
     return dclip_check_launch("dclip_gemm_tn_acc");
 }

@@ -154,6 +154,7 @@ extern "C" int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* r
     const int nv = (int)((D + 255) / 256);
     const dim3 grid((unsigned)((M + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
+    TraceScope tr(DCLIP_TRACE_LAYERNORM, 8.0 * (double)M * D, (double)M * D * (4.0 + (out_f32 ? 4.0 : 2.0)), stream);
     LN_DISPATCH(nv,
         if (out_f32) hipLaunchKernelGGL((ln_fwd_kernel<NV, true>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps);
         else hipLaunchKernelGGL((ln_fwd_kernel<NV, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps));

@@ -407,6 +407,8 @@ extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const 
     a.stats = (float*)w; w += align_up((size_t)6 * B * 4);
     a.scal = (float*)w;
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic HBM bytes: read 4*B*E*4 + write 2*B*E*4 ; the [B,B] logits contribute none
+    TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 6.0 : 3.0) * (double)B * E * 4.0, stream);
     if (hipMemsetAsync(a.scal, 0, NSC * sizeof(float), st) != hipSuccess) {
         dclip_set_error("dclip_distill_loss: memset failed");
         return DCLIP_ELAUNCH;

@@ -209,6 +209,13 @@ int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t 
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
                            const float* d_last_representation, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Launch trace (profiling only; process-global): between begin and end every GEMM / LayerNorm-forward / loss call is
+ * bracketed by HIP events on the stream it is launched on.  trace_end writes (kind, ms, algorithmic flops, algorithmic
+ * bytes) per call and returns the number of calls seen.  kind: 0 gemm_nt, 1 gemm_tn_acc, 2 layernorm_fwd, 3 distill_loss. */
+int dclip_trace_begin(int64_t max_records);
+int64_t dclip_trace_end(int32_t* kind, float* ms, double* flops, double* bytes, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif
