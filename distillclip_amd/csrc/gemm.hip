@@ -16,6 +16,8 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int SUB = 1024;                       // bytes of one [16 x 32] bf16 sub-tile
 constexpr int TILE_BYTES = (BM / 16) * (BK / 32) * SUB;   // 16 KiB per operand per stage
+constexpr int CLD = BN + 4;                     // f32 row stride of the C tile staged through LDS in the epilogue
+constexpr int NT_LDS = (4 * TILE_BYTES > BM * CLD * 4) ? 4 * TILE_BYTES : BM * CLD * 4;
 
 struct GemmNT {
     const bf16_t* A; int64_t lda;
@@ -106,32 +108,80 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         }
     }
 
-    // epilogue: acc[i][j][r] is C[row = i*16 + (lane>>4)*4 + r][col = j*16 + (lane&15)] of the wave's 64x64 tile
-    const int colb = n0 + wn * 64 + (lane & 15);
-    const int rowb = m0 + wm * 64 + (lane >> 4) * 4;
+    // epilogue.  acc[i][j][r] is C[row = i*16 + (lane>>4)*4 + r][col = j*16 + (lane&15)] of the wave's 64x64 tile: storing
+    // from that layout means 2-byte scattered stores.  Stage the 128x128 f32 tile through LDS (the operand buffers are
+    // dead now) and run bias / activation / residual on row-contiguous 8-element vectors (16-byte loads and stores).
+    __syncthreads();
+    float* cs = (float*)smem;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = colb + j * 16;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rowb + i * 16 + r;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bias;
-                const int64_t orow = row;
-                if (p.row_group > 0) v += p.rowadd[(int64_t)(row % p.row_group) * p.N + col];
-                const int64_t o = orow * p.ldc + col;
-                if (p.aux_out) p.aux_out[o] = f2bf(v);
-                if (ACT == 1) v = quick_gelu_f(v);
-                if (ACT == 2) v = gelu_erf_f(v);
-                if (ACT == 3) v *= dgelu_erf_f(bf2f(p.aux_in[o]));
-                if (p.residual) v += p.residual[orow * p.ldr + col];
-                if (OUT_F32) ((float*)p.C)[o] = v;
-                else ((bf16_t*)p.C)[o] = f2bf(v);
-            }
+            for (int r = 0; r < 4; ++r)
+                cs[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    const int cc = (tid & 15) * 8;
+    const int col = n0 + cc;
+    if (col >= p.N) return;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rl = (tid >> 4) + it * 16;
+        const int row = m0 + rl;
+        if (row >= p.M) break;
+        float v[8];
+        {
+            const float4 c0 = *(const float4*)(cs + rl * CLD + cc), c1 = *(const float4*)(cs + rl * CLD + cc + 4);
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+        if (p.row_group > 0) {
+            const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
+            const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+        }
+        const int64_t o = (int64_t)row * p.ldc + col;
+        if (p.aux_out) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
+            *(bf16x8*)(p.aux_out + o) = z;
+        }
+        if (ACT == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(v[e]);
+        }
+        if (ACT == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+        }
+        if (ACT == 3) {
+            const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
+        }
+        if (p.residual) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (OUT_F32) {
+            float* cp = (float*)p.C + o;
+            *(float4*)cp = float4{v[0], v[1], v[2], v[3]};
+            *(float4*)(cp + 4) = float4{v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+            *(bf16x8*)((bf16_t*)p.C + o) = ov;
         }
     }
 }
@@ -284,7 +334,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 template <int ACT>
 int launch_nt(const GemmNT& p, bool out_f32, hipStream_t st) {
     const int grid = p.tiles_m * p.tiles_n;
-    const size_t lds = 4 * TILE_BYTES;
+    const size_t lds = NT_LDS;
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, true>), dim3(grid), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<ACT, false>), dim3(grid), dim3(256), lds, st, p);
     return dclip_check_launch("dclip_gemm_nt");
@@ -301,6 +351,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     DCLIP_REQUIRE(K % BK == 0, "dclip_gemm_nt: K=%ld must be a multiple of %d", (long)K, BK);
     DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
                   "dclip_gemm_nt: operand rows must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
+    DCLIP_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0, "dclip_gemm_nt: N and ldc must be multiples of 8 and C 16-byte aligned (N=%ld ldc=%ld)", (long)N, (long)ldc);
+    DCLIP_REQUIRE(!residual || (ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "dclip_gemm_nt: residual rows must be 16-byte aligned");
     DCLIP_REQUIRE(act >= 0 && act <= 3, "dclip_gemm_nt: bad activation code %d", act);
     DCLIP_REQUIRE(act != DCLIP_ACT_DGELU || aux_in, "dclip_gemm_nt: DGELU needs aux_in");
     DCLIP_REQUIRE(row_group == 0 || rowadd, "dclip_gemm_nt: row_group needs rowadd");
