@@ -307,132 +307,176 @@ struct SoftmaxBwd {
     int B, N, Np;
 };
 
+// B fragment of v_mfma_f32_32x32x16_bf16 from a k-major LDS tile (rows = contraction index, 32 columns from x0,
+// 16 rows from r0): lane (col = l & 31, k = 8*(l >> 5) + e).  Each 16-lane group does two ds_read_b64_tr_b16.
+template <int ROWB>
+__device__ __forceinline__ bf16x8 tr_frag32(const char* tile, int r0, int x0, int lane) {
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const char* a0 = tile + (r0 + 8 * (g4 >> 1) + q) * ROWB + (x0 + 16 * (g4 & 1) + 4 * pp) * 2;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
+    return u.v;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+// Head-mixing softmax backward, everything matrix-shaped on v_mfma_f32_32x32x16_bf16 (one wave per (b, query row)):
+//   Cw[g,h] = sum_j dR[g,j] P[h,j]                (this row's dW_w contribution; also gives the softmax row sums:)
+//   rs[h]   = sum_j P[h,j] dP[h,j] = sum_g Ww[g,h] Cw[g,h]
+//   dP = Ww^T dR ; dA = P o (dP - rs) ; dS = Wl^T dA ; dWl += dA S^T
+// Tiles [32 heads][COLS keys] bf16 live in wave-private LDS; dA feeds the second mix straight from the accumulator
+// registers (guide §3 "An accumulator tile as the next MFMA's operand": Wl^T is pre-permuted in k).
 template <int H, int NS>
-__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(SoftmaxBwd p) {
-    constexpr int COLS = 64 * NS;               // keys per LDS row
-    constexpr int ROWB = COLS * 2 + 16;         // bytes per LDS row (+16: spreads the 32 rows over banks)
+__global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p) {
+    constexpr int COLS = 64 * NS, ROWB = COLS * 2 + 16, NCT = COLS / 32, TILE = 32 * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* xa = smem + wave * (2 * 32 * ROWB);   // [32][COLS] "g" operand
-    char* xb = xa + 32 * ROWB;                  // [32][COLS] "h" operand
-    const bool mix = p.Wl != nullptr;           // student path (both mixes) ; teacher never runs backward
-    if (mix) {
-        // rows H..31 stay zero for the whole kernel
-        for (int idx = lane; idx < 2 * 32 * ROWB / 4; idx += 64) ((unsigned*)xa)[idx] = 0u;
+    char* tR = smem + wave * 3 * TILE;
+    char* tP = tR + TILE;
+    char* tS = tP + TILE;
+    for (int idx = lane; idx < 3 * TILE / 16; idx += 64) ((u32x4*)tR)[idx] = u32x4{0u, 0u, 0u, 0u};
+    const int hh = lane >> 5, c = lane & 31;
+    bf16x8 aWw[2], aWl[2], aI[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = 16 * s + 8 * hh + e;                               // natural k order
+            const int rho = 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);        // k order of an accumulator-as-operand
+            aWw[s][e] = f2bf((g < H && c < H) ? p.Ww[g * H + c] : 0.f);      // A[h = c][k = g]   = Ww[g][h]
+            aWl[s][e] = f2bf((rho < H && c < H) ? p.Wl[rho * H + c] : 0.f);  // A[h' = c][k = g]  = Wl[g][h']
+            aI[s][e] = f2bf(g == c ? 1.f : 0.f);
+        }
+    float wwc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        wwc[r] = (g < H && c < H) ? p.Ww[g * H + c] : 0.f;
     }
     f32x16 accw = {0}, accl = {0};
+    const int64_t hs = (int64_t)p.N * p.Np;
+    const int rows = p.B * p.N;
+    const int nchunk = p.Np >> 3, total = H * nchunk;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int b = row / p.N, i = row % p.N;
+        const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < total; idx += 64) {
+            const int h = idx / nchunk, ck = idx - h * nchunk;
+            const int64_t src = base + h * hs + ck * 8;
+            *(u32x4*)(tR + h * ROWB + ck * 16) = *(const u32x4*)(p.dR + src);
+            *(u32x4*)(tP + h * ROWB + ck * 16) = *(const u32x4*)(p.P + src);
+            const float4 s0 = *(const float4*)(p.S + src), s1 = *(const float4*)(p.S + src + 4);
+            *(bf16x8*)(tS + h * ROWB + ck * 16) = bf16x8{f2bf(s0.x), f2bf(s0.y), f2bf(s0.z), f2bf(s0.w),
+                                                         f2bf(s1.x), f2bf(s1.y), f2bf(s1.z), f2bf(s1.w)};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // Cw = dR P^T
+        f32x16 cw = {0};
+#pragma unroll
+        for (int ks = 0; ks < COLS / 16; ++ks) {
+            const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
+            cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tR + off), *(const bf16x8*)(tP + off), cw, 0, 0, 0);
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(wwc[r], cw[r], part);
+        part += __shfl_xor(part, 32);                      // lanes h and h + 32 now hold rs[h]
+        // dP = Ww^T dR and P in accumulator layout (row h in registers, key j on the lane)
+        f32x16 dp[NCT], pa[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            dp[ct] = f32x16{0}; pa[ct] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dp[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWw[s], tr_frag32<ROWB>(tR, 16 * s, 32 * ct, lane), dp[ct], 0, 0, 0);
+                pa[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[s], tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), pa[ct], 0, 0, 0);
+            }
+        }
+        accw += cw;
+        // dA = P o (dP - rs[h]) ; row of register r is h = (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h0 = (r & 3) + 8 * (r >> 2);
+            const float rs = hh ? lane_bcast(part, h0 + 4) : lane_bcast(part, h0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) dp[ct][r] = pa[ct][r] * (dp[ct][r] - rs);       // dp now holds dA
+        }
+        // dA -> LDS rows (over the dR tile, which is dead) for the dW_l product
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) *(bf16_t*)(tR + h * ROWB + (32 * ct + c) * 2) = f2bf(dp[ct][r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < COLS / 16; ++ks) {
+            const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tR + off), *(const bf16x8*)(tS + off), accl, 0, 0, 0);
+        }
+        // dS = Wl^T dA, B operand straight from the dA accumulator registers
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x16 ds = {0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 bf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[e] = f2bf(dp[ct][8 * s + e]);
+                ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf, ds, 0, 0, 0);
+            }
+            const int j = 32 * ct + c;
+            if (j < p.Np) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (h < H) p.dS[base + h * hs + j] = f2bf(ds[r]);
+                }
+            }
+        }
+    }
+    // accumulators: element (g = (r&3) + 8*(r>>2) + 4*hh, h = c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (g < H && c < H) {
+            if (p.dWw) unsafeAtomicAdd(p.dWw + g * H + c, accw[r]);
+            if (p.dWl) unsafeAtomicAdd(p.dWl + g * H + c, accl[r]);
+        }
+    }
+}
+
+// plain multi-head softmax backward (no head mixing): dS = P o (dR - sum_j P dR), one wave per (b, query row)
+template <int H, int NS>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_plain_kernel(SoftmaxBwd p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t hs = (int64_t)p.N * p.Np;
     const int rows = p.B * p.N;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const int b = row / p.N, i = row % p.N;
         const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
-        float dr[NS][H], pv[NS][H];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int j = lane + 64 * s;
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                dr[s][h] = j < p.N ? bf2f(p.dR[base + h * hs + j]) : 0.f;
-                pv[s][h] = j < p.N ? bf2f(p.P[base + h * hs + j]) : 0.f;
-            }
-        }
-        if (mix) {
-            // dWw += dR_g P_h : stage both as bf16 rows [g][j] / [h][j]
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    *(bf16_t*)(xa + h * ROWB + (lane + 64 * s) * 2) = f2bf(dr[s][h]);
-                    *(bf16_t*)(xb + h * ROWB + (lane + 64 * s) * 2) = f2bf(pv[s][h]);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < COLS / 16; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(xa + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
-                const bf16x8 bf = *(const bf16x8*)(xb + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
-                accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accw, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // dP = Ww^T dR
-        float da[NS][H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            float t[NS];
-            float rs = 0.f;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float dp;
-                if (p.Ww) {
-                    dp = 0.f;
-#pragma unroll
-                    for (int g = 0; g < H; ++g) dp = fmaf(p.Ww[g * H + h], dr[s][g], dp);
-                } else {
-                    dp = dr[s][h];
-                }
-                t[s] = dp;
-                rs += dp * pv[s][h];
-            }
-            rs = wave_sum(rs);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) da[s][h] = pv[s][h] * (t[s] - rs);
-        }
-        if (mix) {
-            float sv[NS][H];
+            float dr[NS], pv[NS], rs = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int j = lane + 64 * s;
-#pragma unroll
-                for (int h = 0; h < H; ++h) sv[s][h] = j < p.N ? p.S[base + h * hs + j] : 0.f;
+                dr[s] = j < p.N ? bf2f(p.dR[base + h * hs + j]) : 0.f;
+                pv[s] = j < p.N ? bf2f(p.P[base + h * hs + j]) : 0.f;
+                rs += dr[s] * pv[s];
             }
-            __builtin_amdgcn_wave_barrier();
+            rs = wave_sum(rs);
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    *(bf16_t*)(xa + h * ROWB + (lane + 64 * s) * 2) = f2bf(da[s][h]);
-                    *(bf16_t*)(xb + h * ROWB + (lane + 64 * s) * 2) = f2bf(sv[s][h]);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < COLS / 16; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(xa + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
-                const bf16x8 bf = *(const bf16x8*)(xb + (lane & 31) * ROWB + (ks * 16 + (lane >> 5) * 8) * 2);
-                accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accl, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // dS = Wl^T dA
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int j = lane + 64 * s;
-            if (j < p.Np) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    float ds;
-                    if (p.Wl) {
-                        ds = 0.f;
-#pragma unroll
-                        for (int g = 0; g < H; ++g) ds = fmaf(p.Wl[g * H + h], da[s][g], ds);
-                    } else {
-                        ds = da[s][h];
-                    }
-                    p.dS[base + h * hs + j] = f2bf(j < p.N ? ds : 0.f);
-                }
-            }
-        }
-    }
-    if (mix) {
-        // acc[reg] is element (g = (reg&3) + 8*(reg>>2) + 4*(lane>>5), h = lane&31)
-        const int hcol = lane & 31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int g = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (g < H && hcol < H) {
-                if (p.dWw) unsafeAtomicAdd(p.dWw + g * H + hcol, accw[r]);
-                if (p.dWl) unsafeAtomicAdd(p.dWl + g * H + hcol, accl[r]);
+            for (int s = 0; s < NS; ++s) {
+                const int j = lane + 64 * s;
+                if (j < p.Np) p.dS[base + h * hs + j] = f2bf(pv[s] * (dr[s] - rs));
             }
         }
     }
@@ -521,8 +565,12 @@ extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const float
     int blocks = (int)((B * N + 3) / 4);
     if (blocks > 2048) blocks = 2048;
     const int ns = N > 64 ? 2 : 1;
-    const size_t lds = 4 * 2 * 32 * (64 * ns * 2 + 16);
     hipStream_t st = (hipStream_t)stream;
-    SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
+    if (Wl) {
+        const size_t lds = (size_t)4 * 3 * 32 * (64 * ns * 2 + 16);
+        SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_mix_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
+    } else {
+        SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_plain_kernel<HH, NSS>), dim3(blocks), dim3(256), 0, st, p));
+    }
     return dclip_check_launch("dclip_attn_softmax_bwd");
 }
