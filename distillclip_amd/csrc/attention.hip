@@ -567,6 +567,9 @@ extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const float
     const int ns = N > 64 ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
     if (Wl) {
+        // ~280 registers -> one resident workgroup per CU: launch one persistent workgroup per CU so the per-workgroup
+        // setup (LDS zero-fill, constant Ww / Wl fragments) is amortised over all its rows
+        if (blocks > 256) blocks = 256;
         const size_t lds = (size_t)4 * 3 * 32 * (64 * ns * 2 + 16);
         SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_mix_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
     } else {

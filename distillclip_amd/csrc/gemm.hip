@@ -9,6 +9,8 @@
 // K-tile.  The LDS image is made of 1 KiB [16 rows x 32 k] sub-tiles (one per wave-instruction) with the
 // st_16x32 XOR swizzle (byte ^= ((byte >> 9) & 1) << 5) applied on the SOURCE address and again on the
 // ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
+#include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -187,6 +189,243 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// gemm_nt256: 256x256x64 tile, 8 waves (2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles, 128 accumulator registers),
+// one workgroup per CU (128 KiB LDS).  Structure after the guide's "256^2 8-phase" template, with our own schedule:
+//   * LDS = [2 parities][A_lo, A_hi, B_lo, B_hi] half-tiles of 128 rows x 64 k (16 KiB each, same swizzled sub-tile image
+//     as above); every half-tile is staged by all 8 waves (2 global_load_lds per wave).
+//   * a K-tile is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile).  Fragment reads per phase:
+//       phase 0: A rows 0-63 (8 frags) + B cols 0-31 (4)   phase 1: B cols 32-63 (4)   phase 2: A rows 64-127 (8)   phase 3: -
+//     quadrant order (0,0) (0,1) (1,1) (1,0), both B fragment sets stay in registers.
+//   * the load stream runs 5 phases ahead: phase k issues half-tile l = k + 5, l = 4*tile + {B_lo, B_hi, A_lo, A_hi}.
+//     WAR: the buffer's previous tile was last read >= 2 barriers earlier (B: phase 1, A: phase 2 of tile - 2).
+//     RAW: a counted s_waitcnt vmcnt(2) in phase 3 (all but the just-issued half-tile landed) + the two barriers that
+//     separate it from phase 0 of the next tile.  vmcnt never drains to 0 inside the loop.
+//   * the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one barrier apart: while one group issues its
+//     MFMAs the other issues its ds_reads / LDS-DMA, so the matrix pipe of every SIMD stays fed.
+// ------------------------------------------------------------------------------------------------------
+constexpr int HT = 16384;                       // bytes of a half-tile
+constexpr int CLD2 = 256 + 4;                   // f32 row stride of the 64-row C slab staged in the epilogue
+
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max, int k0,
+                                           char* buf, int wave, int lane) {
+    const int L = lane * 16;
+    const int X = swz(L);
+    const int r = X >> 6, c = (X >> 4) & 3;
+    int row = row0 + wave * 16 + r;             // the wave's row-block = wave (8 row-blocks per half-tile)
+    row = row < rows_max ? row : rows_max - 1;
+    const bf16_t* src = G + (int64_t)row * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (wave * 2 + 0) * SUB), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(buf + (wave * 2 + 1) * SUB), 16, 0, 0);
+}
+
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow, int row, int col, const float (&bias)[8]) {
+    float v[8];
+    {
+        const float4 c0 = *(const float4*)crow, c1 = *(const float4*)(crow + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+    if (p.row_group > 0) {
+        const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
+        const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
+        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
+    const int64_t o = (int64_t)row * p.ldc + col;
+    if (p.aux_out) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
+        *(bf16x8*)(p.aux_out + o) = z;
+    }
+    if (ACT == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(v[e]);
+    }
+    if (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+    }
+    if (ACT == 3) {
+        const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
+    }
+    if (p.residual) {
+        const float* rp = p.residual + (int64_t)row * p.ldr + col;
+        const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (OUT_F32) {
+        float* cp = (float*)p.C + o;
+        *(float4*)cp = float4{v[0], v[1], v[2], v[3]};
+        *(float4*)(cp + 4) = float4{v[4], v[5], v[6], v[7]};
+    } else {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+        *(bf16x8*)((bf16_t*)p.C + o) = ov;
+    }
+}
+
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = p.K / BK;
+    const int nload = 4 * nk;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_lo, 3 A_hi ; LDS slot (tile & 1) * 4 + w
+    auto issue = [&](int l) {
+        const int tile = l >> 2, w = l & 3;
+        char* buf = smem + ((tile & 1) * 4 + w) * HT;
+        if (w < 2) stage_half(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, buf, wave, lane);
+        else stage_half(p.A, p.lda, m0 + (w - 2) * 128, p.M, tile * BK, buf, wave, lane);
+    };
+    const int npro = nload < 5 ? nload : 5;
+    for (int l = 0; l < npro; ++l) issue(l);
+    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
+
+    const int fragoff = swz((lane & 15) * 64 + (lane >> 4) * 16);
+    const int a_off = (2 + wr) * HT;                         // this wave's A half
+    const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * 4 * HT;
+        const char* ap = base + a_off + fragoff;
+        const char* bp = base + b_off + fragoff;
+        const int k4 = kt * 4;
+        // ---------------- phase 0 : quadrant (rows 0-63, cols 0-31) ----------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b0[j][kb] = *(const bf16x8*)(bp + (j * 2 + kb) * SUB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + (i * 2 + kb) * SUB);
+        if (k4 + 5 < nload) issue(k4 + 5);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 1 : quadrant (rows 0-63, cols 32-63) ----------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b1[j][kb] = *(const bf16x8*)(bp + ((2 + j) * 2 + kb) * SUB);
+        if (k4 + 6 < nload) issue(k4 + 6);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 2 : quadrant (rows 64-127, cols 32-63) ----------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + ((4 + i) * 2 + kb) * SUB);
+        if (k4 + 7 < nload) issue(k4 + 7);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[4 + i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 3 : quadrant (rows 64-127, cols 0-31) ----------------
+        if (k4 + 8 < nload) { issue(k4 + 8); WAIT_VMCNT(2); }
+        else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
+
+    // epilogue: 4 slabs of 64 rows (32 rows of each wave group) staged through LDS, row-contiguous 8-wide vectors
+    float* cs = (float*)smem;
+    const int cc = (tid & 31) * 8;
+    const int col = n0 + cc;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias && col < p.N) {
+        const float4 q0 = *(const float4*)(p.bias + col), q1 = *(const float4*)(p.bias + col + 4);
+        bias[0] = q0.x; bias[1] = q0.y; bias[2] = q0.z; bias[3] = q0.w; bias[4] = q1.x; bias[5] = q1.y; bias[6] = q1.z; bias[7] = q1.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+        // slab row = wr * 32 + (0..31)  <->  tile row wr * 128 + q * 32 + (0..31)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cs[(wr * 32 + i * 16 + (lane >> 4) * 4 + r) * CLD2 + wc * 64 + j * 16 + (lane & 15)] = acc[q * 2 + i][j][r];
+        __syncthreads();
+        if (col < p.N) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int sl = (tid >> 5) + it * 16;                     // slab row 0..63
+                const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+                if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // wgrad: out[P,Q] += sum_m A[m,P] * B[m,Q].  Both operands are "k-major" (the contraction index m is the row),
 // so MFMA fragments (8 consecutive k per lane) need a transpose: tiles are staged row-major into LDS through
 // registers (rows padded to 288 B) and read back with ds_read_b64_tr_b16 (guide T10).
@@ -331,8 +570,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     unsafeAtomicAdd(db + col, (s0 + s1) + (s2 + s3));
 }
 
+bool use_256(const GemmNT& p) {
+    static const int mode = [] { const char* e = getenv("DCLIP_GEMM256"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || p.M < 1024 || p.N < 256) return false;
+    if (mode == 2) return true;
+    // wave quantisation on 256 CUs: the 256^2 kernel runs 1 workgroup / CU, the 128^2 kernel 2 / CU.  Measured intrinsic
+    // advantage of the 256^2 pipeline at equal fill: ~1.2x (tools/diag/gemm_shapes.py).
+    const double t256 = (double)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const double t128 = (double)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const double e256 = t256 / (ceil(t256 / 256.0) * 256.0), e128 = t128 / (ceil(t128 / 512.0) * 512.0);
+    return e256 * 1.2 > e128;
+}
+
 template <int ACT>
-int launch_nt(const GemmNT& p, bool out_f32, hipStream_t st) {
+int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
+    if (use_256(p)) {
+        p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+        const int grid256 = p.tiles_m * p.tiles_n;
+        const size_t lds256 = 8 * HT;
+        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true>), dim3(grid256), dim3(512), lds256, st, p);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false>), dim3(grid256), dim3(512), lds256, st, p);
+        return dclip_check_launch("dclip_gemm_nt");
+    }
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NT_LDS;
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, true>), dim3(grid), dim3(256), lds, st, p);
