@@ -4,6 +4,7 @@ Same constructor / forward / training_step / configure_optimizers / load_weight 
 LightningModule, on a plain nn.Module (Lightning, wandb and torchmetrics are absent here; validation metrics are the
 "next" row N3 of SURVEY.md §8f).
 """
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -59,6 +60,8 @@ class DualDistillModel(nn.Module):
         self.k_list = [1, 3, 5, 10, 20, 50]
         self.current_epoch = 0
         self._sync = None
+        self._streams = None
+        self.multi_stream = os.environ.get('DCLIP_MULTI_STREAM', '1') != '0'
 
     def towers(self):
         return [self.student.image_encoder._tower, self.student.text_encoder._tower]
@@ -66,9 +69,35 @@ class DualDistillModel(nn.Module):
     def forward(self, inputs) -> Tuple[CLIPOutput, CLIPOutput]:
         # reference :106-112.  The batch is (image, text) while CLIPModel.forward takes (text, image).
         image, text = inputs
-        student_outs = self.student(text, image, self.need_return_para)
-        with torch.no_grad():      # the reference only relies on requires_grad=False; values are identical
-            teacher_outs = self.teacher(text, image, self.need_return_para)
+        if not (self.multi_stream and image.is_cuda):
+            student_outs = self.student(text, image, self.need_return_para)
+            with torch.no_grad():  # the reference only relies on requires_grad=False; values are identical
+                teacher_outs = self.teacher(text, image, self.need_return_para)
+        else:
+            # The four towers are independent until the loss: issue each on its own HIP stream so their kernels fill each
+            # other's tail waves and hide the latency-bound attention kernels.  autograd replays each tower's backward on
+            # the stream its forward ran on, so the two student backwards overlap as well.
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream() for _ in range(4)]
+            co = self.need_return_para
+            jobs = ((self.teacher.image_encoder, image, False), (self.teacher.text_encoder, text, False),
+                    (self.student.image_encoder, image, True), (self.student.text_encoder, text, True))
+            outs = []
+            for st, (enc, x, grad) in zip(self._streams, jobs):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    if grad:
+                        o = enc(x, co)
+                    else:
+                        with torch.no_grad():
+                            o = enc(x, co)
+                o.last_representation.record_stream(main)
+                outs.append(o)
+            for st in self._streams:
+                main.wait_stream(st)
+            teacher_outs = CLIPOutput(visual_output=outs[0], text_output=outs[1])
+            student_outs = CLIPOutput(visual_output=outs[2], text_output=outs[3])
         if self.hparams.norm:
             raise NotImplementedError('norm=True (pre-normalised representations) is False in every shipped config')
         return student_outs, teacher_outs
