@@ -152,11 +152,15 @@ def main():
         # recorded on the launch stream by the library's trace hooks (include/dclip.h: dclip_trace_*)
         import ctypes
         cap = 20000
-        lib().dclip_trace_begin(cap)
         nprobe = 2
+        multi, model.multi_stream = model.multi_stream, False      # one stream: event intervals then bracket one kernel each
+        step()
+        torch.cuda.synchronize()
+        lib().dclip_trace_begin(cap)
         for _ in range(nprobe):
             step()
         torch.cuda.synchronize()
+        model.multi_stream = multi
         kind = (ctypes.c_int32 * cap)()
         ms = (ctypes.c_float * cap)()
         fl = (ctypes.c_double * cap)()
@@ -171,8 +175,14 @@ def main():
         names = {0: 'gemm_nt_kernel', 1: 'gemm_tn_kernel', 2: 'ln_fwd_kernel', 3: 'distill_loss'}
         g = agg.get(0, [1, 1.0, 0.0, 0.0])
         achieved = g[2] / (g[1] * 1e-3) / 1e12
-        roofline = {'kernel': 'gemm_nt_kernel', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+        traffic = None                                          # HBM bytes / launch from the committed PMC passes of this command
+        import glob
+        tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+        if tj:
+            traffic = json.load(open(tj[-1])).get('gemm_nt', {}).get('hbm_bytes_per_launch')
+        roofline = {'kernel': 'gemm_nt (gemm_nt_kernel 128x128 + gemm_nt256_kernel 256x256)', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': g[3] / g[0],
                     'launches_per_step': g[0] // nprobe, 'avg_launch_us': round(g[1] / g[0] * 1e3, 2),
                     'flop_per_launch': g[2] / g[0],
                     'others': {names.get(k, str(k)): {'launches_per_step': v[0] // nprobe, 'ms_per_step': round(v[1] / nprobe, 3),

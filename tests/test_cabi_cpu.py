@@ -1,0 +1,87 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads without a GPU, exports every symbol include/dclip.h
+declares, rejects bad arguments before touching the device, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from distillclip_amd._lib import lib, _HEADER
+    l = lib()
+    declared = set(re.findall(r'\b(dclip_\w+)\s*\(', open(_HEADER).read()))
+    declared -= {'dclip_encoder_cfg'}
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(l._dll, name), name
+    assert l.dclip_version() == 1 and l.dclip_arch() == b'gfx950'
+
+
+def test_argument_validation_happens_on_host():
+    from distillclip_amd._lib import lib
+    l = lib()
+    with pytest.raises(ValueError, match='multiple of 64'):
+        l.dclip_gemm_nt(16, 8, 16, 8, 16, 8, 4, 8, 48, 1.0, None, 0, None, None, None, 0, 0, 0, None, None)
+    with pytest.raises(ValueError, match='null'):
+        l.dclip_gemm_nt(None, 8, 16, 8, 16, 8, 4, 8, 64, 1.0, None, 0, None, None, None, 0, 0, 0, None, None)
+    with pytest.raises(ValueError):
+        l.dclip_layernorm_fwd(16, 4, None, 16, 16, 16, 4, 0, None, None, 4, 2048, 1e-5, None)     # D > 1024
+    with pytest.raises(ValueError, match='head dim'):
+        l.dclip_attn_nt(16, 8, 16, 8, 16, 1, 1, 1, 8, 8, 48, 1.0, None)
+    assert l.dclip_distill_loss_workspace(512, 512) > 6 * 512 * 512 * 4
+
+
+def test_encoder_plan_is_host_side():
+    """dclip_encoder_create / workspace sizing never touch the device: usable here to size buffers."""
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    from distillclip_amd._lib import lib
+    v = RepeatVisionTransformer(img_size=224, patch_size=32, out_dim=512, embed_dim=768, depth=6, num_heads=24, qkv_bias=True,
+                                repeated_times=2, use_transform=True)
+    t = RepeatTextTransformer(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)
+    for m, n_expected in ((v, 4 + 3 * (8 + 2 * 6) + 4), (t, 4 + 2 * (8 + 2 * 6) + 4)):
+        h = m._tower._handle
+        assert lib().dclip_encoder_num_params(h) == n_expected
+        infer = lib().dclip_encoder_workspace_bytes(h, 512, 0)
+        train = lib().dclip_encoder_workspace_bytes(h, 512, 1)
+        assert 0 < infer < train < 40 * 2 ** 30
+        assert lib().dclip_encoder_wcache_bytes(h) > 0
+    with pytest.raises(ValueError, match='head dim'):
+        RepeatVisionTransformer(img_size=224, patch_size=32, out_dim=512, embed_dim=768, depth=2, num_heads=8,
+                                repeated_times=2, use_transform=True)
+
+
+def test_state_dict_keys_match_reference_layout():
+    from distillclip_amd import synth
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer, ImageEncoder, TextEncoder
+    v = RepeatVisionTransformer(img_size=224, patch_size=32, out_dim=512, embed_dim=768, depth=6, num_heads=24, qkv_bias=True,
+                                repeated_times=2, use_transform=True)
+    assert set(v.state_dict()) == set(synth.student_image_state(0)) and len(v.state_dict()) == 68
+    t = RepeatTextTransformer(depth=4, repeated_times=2, use_transform=True)
+    assert set(t.state_dict()) == set(synth.student_text_state(0)) and len(t.state_dict()) == 44
+    ti = ImageEncoder(False, dict(input_resolution=224, patch_size=32, width=768, layers=12, heads=12, output_dim=512))
+    assert set(ti.state_dict()) == set(synth.teacher_image_state(0, layers=12))
+    tt = TextEncoder(512, 12, 8, 77, None, 49408, 512, is_student=False)
+    assert set(tt.state_dict()) == set(synth.teacher_text_state(0))
+
+
+def test_no_cpu_fallback():
+    from distillclip_amd import ops
+    from distillclip_amd.model.component import RepeatTextTransformer
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.gemm_nt(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+    t = RepeatTextTransformer(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2,
+                              repeated_times=2, use_transform=True)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        t(torch.zeros(2, 13, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'distillclip_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, f)
