@@ -49,33 +49,51 @@ __global__ __launch_bounds__(256) void attn_nt_kernel(AttnMM p) {
     const int nt = (p.N + 15) >> 4;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     constexpr int KS = HD / 32;
-    for (int it = 0; it < nt; ++it) {
-        const int ia = min(it * 16 + fr, p.N - 1);
-        bf16x8 af[KS];
+    constexpr int NTM = 8;                               // N <= 128
+    // the B-side fragments (all key tiles) are the same for every query tile: load them once, keep them in registers
+    bf16x8 bfr[NTM][KS];
+#pragma unroll
+    for (int jt = 0; jt < NTM; ++jt)
+        if (jt < nt) {
+            const int jb = min(jt * 16 + fr, p.N - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bfr[jt][ks] = *(const bf16x8*)(Bm + (int64_t)jb * p.ldb + ks * 32 + fk);
+        }
+    bf16x8 af[KS], afn[KS];
+    {
+        const int ia = min(fr, p.N - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
-        for (int jt = 0; jt < nt; ++jt) {
-            const int jb = min(jt * 16 + fr, p.N - 1);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    }
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) {                               // prefetch the next query tile under this tile's MFMAs / stores
+            const int ia = min((it + 1) * 16 + fr, p.N - 1);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 bf = *(const bf16x8*)(Bm + (int64_t)jb * p.ldb + ks * 32 + fk);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc, 0, 0, 0);
-            }
-            const int j = jt * 16 + fr;
-            if (j < p.Np) {
+            for (int ks = 0; ks < KS; ++ks) afn[ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = it * 16 + (lane >> 4) * 4 + r;
-                    if (i < p.N) {
-                        const float v = j < p.N ? acc[r] * p.alpha : 0.f;
-                        const int64_t o = (((int64_t)b * p.H + h) * p.N + i) * p.ldc + j;
-                        if (OUT_F32) ((float*)p.C)[o] = v;
-                        else ((bf16_t*)p.C)[o] = f2bf(v);
+        for (int jt = 0; jt < NTM; ++jt) {
+            if (jt < nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr[jt][ks], acc, 0, 0, 0);
+                const int j = jt * 16 + fr;
+                if (j < p.Np) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = it * 16 + (lane >> 4) * 4 + r;
+                        if (i < p.N) {
+                            const float v = j < p.N ? acc[r] * p.alpha : 0.f;
+                            const int64_t o = (((int64_t)b * p.H + h) * p.N + i) * p.ldc + j;
+                            if (OUT_F32) ((float*)p.C)[o] = v;
+                            else ((bf16_t*)p.C)[o] = f2bf(v);
+                        }
                     }
                 }
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = afn[ks];
     }
 }
 
@@ -127,18 +145,30 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
     const int nt = (p.N + 15) >> 4, nks = n32 >> 5;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     constexpr int DT = HD / 16;
-    for (int it = 0; it < nt; ++it) {
+    constexpr int KSM = NMAX / 32;
+    bf16x8 af[KSM], afn[KSM];
+    auto load_a = [&](int it, bf16x8 (&dst)[KSM]) {
         const int ia = min(it * 16 + fr, p.N - 1);
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            const int j0 = ks * 32 + fk;
+            dst[ks] = (ks < nks && j0 < p.Np) ? *(const bf16x8*)(A + (int64_t)ia * p.lda + j0) : zero_frag();
+        }
+    };
+    load_a(0, af);
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) load_a(it + 1, afn);
         f32x4 acc[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nks; ++ks) {
-            const int j0 = ks * 32 + fk;
-            const bf16x8 af = j0 < p.Np ? *(const bf16x8*)(A + (int64_t)ia * p.lda + j0) : zero_frag();
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const bf16x8 bf = tr_frag<ROWB>(tile, ks * 32, d * 16, lane);
-                acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[d], 0, 0, 0);
+        for (int ks = 0; ks < KSM; ++ks) {
+            if (ks < nks) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const bf16x8 bf = tr_frag<ROWB>(tile, ks * 32, d * 16, lane);
+                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc[d], 0, 0, 0);
+                }
             }
         }
         if (live) {
@@ -151,6 +181,8 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
                     if (i < p.N) C[(int64_t)i * p.ldc + d * 16 + fr] = f2bf(acc[d][r] * p.alpha);
                 }
         }
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) af[ks] = afn[ks];
     }
 }
 

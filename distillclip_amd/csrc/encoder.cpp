@@ -198,7 +198,7 @@ inline int wsplits(int64_t M, int64_t P, int64_t Q) {
 inline int gemm(const void* A, int64_t lda, const void* Bw, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                 const float* bias, int act, const void* aux_in, void* aux_out, const float* res, int64_t ldr, int out_f32,
                 int64_t row_group, const float* rowadd, void* st) {
-    return dclip_gemm_nt(A, lda, Bw, ldb, C, ldc, M, N, K, 1.f, bias, act, aux_in, aux_out, res, ldr, out_f32, row_group, rowadd, st);
+    return dclip_gemm_nt(A, lda, Bw, ldb, C, ldc, M, N, K, 1.f, bias, act, aux_in, aux_out, res, ldr, out_f32, row_group, rowadd, nullptr, st);
 }
 
 }  // namespace
@@ -364,7 +364,10 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, st));
     if (GR(f + 3)) CK(dclip_colsum_acc(w.dout, E, GR(f + 3), B, E, st));
     CK(gemm(w.dout, E, W + p.w_head_t, E, w.dh, D, B, D, E, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, w.Gb, D, GR(f), GR(f + 1), B, D, st));
+    // every LayerNorm backward also emits the column sums of the updated residual gradient = the bias gradient of the
+    // linear that wrote into that residual stream (fc2 of the previous execution / attn.proj of this one)
+    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, w.Gb, D, GR(f), GR(f + 1),
+                           GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
 
     // ---- blocks, last execution first --------------------------------------------------------------------------
     for (int ei = nex - 1; ei >= 0; --ei) {
@@ -376,15 +379,14 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         if (GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.Gb, D, s.u, F, GR(sb.f2w), F, M, D, F, wsplits(M, D, F), st));
-        if (GR(sb.f2b)) CK(dclip_colsum_acc(w.Gb, D, GR(sb.f2b), M, D, st));
-        CK(gemm(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, nullptr, DCLIP_ACT_DGELU, s.z, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_gemm_nt(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_DGELU, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
+                         GR(sb.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
         if (GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s.h2, D, GR(sb.f1w), D, M, F, D, wsplits(M, F, D), st));
-        if (GR(sb.f1b)) CK(dclip_colsum_acc(w.dbig, F, GR(sb.f1b), M, F, st));
         CK(gemm(w.dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, w.Gb, D, GR(sr.n2w), GR(sr.n2b), M, D, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, w.Gb, D, GR(sr.n2w), GR(sr.n2b),
+                               GR(sb.prb), M, D, st));
         // attention: x_mid = x_in + proj(attn(LN1(x_in)))
         if (GR(sb.prw)) CK(dclip_gemm_tn_acc(w.Gb, D, s.ctx, D, GR(sb.prw), D, M, D, D, wsplits(M, D, D), st));
-        if (GR(sb.prb)) CK(dclip_colsum_acc(w.Gb, D, GR(sb.prb), M, D, st));
         bf16_t* dctx = w.dh;
         CK(gemm(w.Gb, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));                   // dR = dO V^T
@@ -395,7 +397,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s.h1, D, GR(sb.qkvw), D, M, 3 * D, D, wsplits(M, 3 * D, D), st));
         if (params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), M, 3 * D, st));
         CK(gemm(w.dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, w.Gb, D, GR(sr.n1w), GR(sr.n1b), M, D, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, w.Gb, D, GR(sr.n1w), GR(sr.n1b),
+                               ei > 0 ? GR(sblock(p, (ei - 1) / p.R).f2b) : nullptr, M, D, st));
     }
 
     // ---- embedding ---------------------------------------------------------------------------------------------

@@ -32,6 +32,7 @@ struct GemmNT {
     bf16_t* aux_out;
     const float* residual; int64_t ldr;
     int row_group; const float* rowadd;
+    float* colsum;                                  // += column sums of the epilogue output (bias gradient), may be null
     int tiles_m, tiles_n;
 };
 
@@ -133,6 +134,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rl = (tid >> 4) + it * 16;
@@ -185,6 +189,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
             *(bf16x8*)((bf16_t*)p.C + o) = ov;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+    }
+    if (p.colsum) {
+        // lanes l, l+16, l+32, l+48 of a wave own the same 8 columns
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = csum[e];
+            x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            if (lane < 16) unsafeAtomicAdd(p.colsum + col + e, x);
+        }
     }
 }
 
@@ -219,7 +234,8 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int64_t
 }
 
 template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow, int row, int col, const float (&bias)[8]) {
+__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow, int row, int col, const float (&bias)[8],
+                                              float (&csum)[8]) {
     float v[8];
     {
         const float4 c0 = *(const float4*)crow, c1 = *(const float4*)(crow + 4);
@@ -267,6 +283,8 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
         for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
         *(bf16x8*)((bf16_t*)p.C + o) = ov;
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] += v[e];
 }
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -402,6 +420,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         const float4 q0 = *(const float4*)(p.bias + col), q1 = *(const float4*)(p.bias + col + 4);
         bias[0] = q0.x; bias[1] = q0.y; bias[2] = q0.z; bias[3] = q0.w; bias[4] = q1.x; bias[5] = q1.y; bias[6] = q1.z; bias[7] = q1.w;
     }
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         __syncthreads();
@@ -419,8 +440,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             for (int it = 0; it < 4; ++it) {
                 const int sl = (tid >> 5) + it * 16;                     // slab row 0..63
                 const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
-                if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias);
+                if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias, csum);
             }
+        }
+    }
+    if (p.colsum && col < p.N) {
+        // lanes l and l + 32 of a wave own the same 8 columns
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = csum[e];
+            x += __shfl_xor(x, 32);
+            if (lane < 32) unsafeAtomicAdd(p.colsum + col + e, x);
         }
     }
 }
@@ -604,7 +634,7 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
 extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                              int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
                              const void* aux_in, void* aux_out, const float* residual, int64_t ldr, int out_f32,
-                             int64_t row_group, const float* rowadd, void* stream) {
+                             int64_t row_group, const float* rowadd, float* colsum_acc, void* stream) {
     DCLIP_REQUIRE(A && B && C, "dclip_gemm_nt: null operand");
     DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "dclip_gemm_nt: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     DCLIP_REQUIRE(K % BK == 0, "dclip_gemm_nt: K=%ld must be a multiple of %d", (long)K, BK);
@@ -620,7 +650,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha; p.bias = bias;
     p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.residual = residual; p.ldr = ldr;
-    p.row_group = (int)row_group; p.rowadd = rowadd;
+    p.row_group = (int)row_group; p.rowadd = rowadd; p.colsum = colsum_acc;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,

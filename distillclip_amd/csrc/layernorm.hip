@@ -66,13 +66,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx_acc,
                                                      int64_t lddx, bf16_t* __restrict__ dx_bf16, int64_t lddb,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
-    __shared__ float red[2][4][LN_MAXV * 256];
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ colsum, int M, int D) {
+    __shared__ float red[3][4][LN_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 dg[NV], db[NV], gm[NV];
+    float4 dg[NV], db[NV], gm[NV], cs[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        dg[i] = db[i] = float4{0.f, 0.f, 0.f, 0.f};
+        dg[i] = db[i] = cs[i] = float4{0.f, 0.f, 0.f, 0.f};
         const int c = (i * 64 + lane) * 4;
         gm[i] = c < D ? *(const float4*)(gamma + c) : float4{0.f, 0.f, 0.f, 0.f};
     }
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 a.z += rs * (g[i].z - c1 - xh[i].z * c2);
                 a.w += rs * (g[i].w - c1 - xh[i].w * c2);
                 *(float4*)o = a;
+                cs[i].x += a.x; cs[i].y += a.y; cs[i].z += a.z; cs[i].w += a.w;
                 if (dx_bf16) {
                     bf16x4 b = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
                     *(bf16x4*)(dx_bf16 + src * lddb + c) = b;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const int c = (i * 64 + lane) * 4;
         *(float4*)&red[0][wave][c] = dg[i];
         *(float4*)&red[1][wave][c] = db[i];
+        *(float4*)&red[2][wave][c] = cs[i];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         if (dgamma) unsafeAtomicAdd(dgamma + c, a);
         if (dbeta) unsafeAtomicAdd(dbeta + c, b);
+        if (colsum) unsafeAtomicAdd(colsum + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
 }
 
@@ -164,7 +167,7 @@ extern "C" int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* r
 extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx,
                                    const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
                                    float* dx_acc, int64_t lddx, void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta,
-                                   int64_t M, int64_t D, void* stream) {
+                                   float* colsum_acc, int64_t M, int64_t D, void* stream) {
     DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx_acc, "dclip_layernorm_bwd: null operand");
     DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
     const int nv = (int)((D + 255) / 256);
@@ -172,7 +175,7 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
     if (blocks > 1024) blocks = 1024;
     hipStream_t st = (hipStream_t)stream;
     LN_DISPATCH(nv,
-        if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, (int)M, (int)D);
-        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, (int)M, (int)D));
+        if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D));
     return dclip_check_launch("dclip_layernorm_bwd");
 }

@@ -22,7 +22,7 @@ def _chk(*ts):
 
 
 def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=None, out=None, out_dtype=torch.bfloat16,
-            alpha=1.0, row_group=0, rowadd=None, out_rows=None):
+            alpha=1.0, row_group=0, rowadd=None, out_rows=None, colsum=None):
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K]^T); see include/dclip.h:dclip_gemm_nt."""
     _chk(a, b, bias, aux_in, aux_out, residual, out, rowadd)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
@@ -36,7 +36,7 @@ def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=No
     ldr = residual.stride(0) if residual is not None else 0
     lib().dclip_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
                         _p(bias), ACT[act], _p(aux_in), _p(aux_out), _p(residual), ldr,
-                        1 if out.dtype == torch.float32 else 0, row_group, _p(rowadd), _stream())
+                        1 if out.dtype == torch.float32 else 0, row_group, _p(rowadd), _p(colsum), _stream())
     return out
 
 
@@ -71,12 +71,12 @@ def layernorm_fwd(x, gamma, beta, *, row_index=None, out_dtype=torch.bfloat16, e
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_acc, *, row_index=None, dx_bf16=None, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_acc, *, row_index=None, dx_bf16=None, dgamma=None, dbeta=None, colsum=None):
     _chk(dy, x, gamma, mean, rstd, dx_acc, dx_bf16, dgamma, dbeta)
     M, D = dy.shape
     lib().dclip_layernorm_bwd(_p(dy), dy.stride(0), 1 if dy.dtype == torch.float32 else 0, _p(x), x.stride(0),
                               _p(row_index), _p(gamma), _p(mean), _p(rstd), _p(dx_acc), dx_acc.stride(0), _p(dx_bf16),
-                              dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(dgamma), _p(dbeta), M, D, _stream())
+                              dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(dgamma), _p(dbeta), _p(colsum), M, D, _stream())
 
 
 def attn_nt(a, lda, bm, ldb, B, H, N, hd, alpha=1.0, out_dtype=torch.float32):

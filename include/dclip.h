@@ -43,11 +43,12 @@ const char* dclip_last_error_string(void);  /* thread-local */
  *   row_group > 0 adds `rowadd` (f32 [row_group, N]) row (r % row_group) to GEMM row r: the positional-embedding
  *   add of the token embedders (reference _common.py:196-202, text_encoder.py:65-66, weight_share_model.py:344-349,
  *   :487-489); for images the caller folds class token and conv bias into the table (see dclip_token_table).
+ *   colsum_acc (f32 [N], may be NULL) += column sums of the stored values (bias gradient of the producing linear).
  */
 int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
                   const void* aux_in, void* aux_out, const float* residual, int64_t ldr, int out_f32,
-                  int64_t row_group, const float* rowadd, void* stream);
+                  int64_t row_group, const float* rowadd, float* colsum_acc, void* stream);
 
 /*
  * dW[P,Q] (f32, ld = ldo) += sum_m A[m,P] * B[m,Q]         (weight gradient of nn.Linear: dY^T · X)
@@ -68,14 +69,16 @@ int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N,
  * fwd: y[r] = LN(x[row_index ? row_index[r] : r]) * gamma + beta ; y is bf16 (out_f32=0) or f32 ; mean/rstd (f32 [M],
  *      nullable) are saved for backward.  D % 4 == 0, D <= 1024.
  * bwd: dx_acc[src(r)] += LN'(dy[r]) (f32, in place: the residual-stream gradient) ; optional bf16 copy of the updated
- *      rows in dx_bf16 ; dgamma / dbeta (f32 [D], nullable) += batch sums.
+ *      rows in dx_bf16 ; dgamma / dbeta (f32 [D], nullable) += batch sums ; colsum_acc (f32 [D], nullable) += column sums
+ *      of the updated dx_acc rows (the bias gradient of the linear that fed this residual stream).
  */
 int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
                         void* y, int64_t ldy, int out_f32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                         void* stream);
 int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx, const int32_t* row_index,
                         const float* gamma, const float* mean, const float* rstd, float* dx_acc, int64_t lddx,
-                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t M, int64_t D, void* stream);
+                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, float* colsum_acc, int64_t M, int64_t D,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Attention building blocks.  q/k/v/ctx are token-major bf16 (row = b*N + n, column = head*hd + d, row stride ld*);

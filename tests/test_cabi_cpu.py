@@ -25,9 +25,9 @@ def test_argument_validation_happens_on_host():
     from distillclip_amd._lib import lib
     l = lib()
     with pytest.raises(ValueError, match='multiple of 64'):
-        l.dclip_gemm_nt(16, 8, 16, 8, 16, 8, 4, 8, 48, 1.0, None, 0, None, None, None, 0, 0, 0, None, None)
+        l.dclip_gemm_nt(16, 8, 16, 8, 16, 8, 4, 8, 48, 1.0, None, 0, None, None, None, 0, 0, 0, None, None, None)
     with pytest.raises(ValueError, match='null'):
-        l.dclip_gemm_nt(None, 8, 16, 8, 16, 8, 4, 8, 64, 1.0, None, 0, None, None, None, 0, 0, 0, None, None)
+        l.dclip_gemm_nt(None, 8, 16, 8, 16, 8, 4, 8, 64, 1.0, None, 0, None, None, None, 0, 0, 0, None, None, None)
     with pytest.raises(ValueError):
         l.dclip_layernorm_fwd(16, 4, None, 16, 16, 16, 4, 0, None, None, 4, 2048, 1e-5, None)     # D > 1024
     with pytest.raises(ValueError, match='head dim'):

@@ -66,8 +66,14 @@ def test_gemm_nt_dgelu():
     z = _rand((M, N), 7)
     zf = z.float().requires_grad_(True)
     torch.nn.functional.gelu(zf).sum().backward()
-    out = ops.gemm_nt(a, b, act='dgelu', aux_in=z, out_dtype=torch.float32)
+    cs = torch.zeros(N, device='cuda')
+    out = ops.gemm_nt(a, b, act='dgelu', aux_in=z, out_dtype=torch.float32, colsum=cs)
     _close(out, (a.float() @ b.float().t()) * zf.grad, 1e-4)
+    _close(cs, out.sum(0), 1e-5)
+    a2, b2 = _rand((2100, 128), 15), _rand((512, 128), 16, 0.2)           # 256x256 kernel path
+    cs2 = torch.zeros(512, device='cuda')
+    o2 = ops.gemm_nt(a2, b2, out_dtype=torch.float32, colsum=cs2)
+    _close(cs2, o2.sum(0), 1e-5)
 
 
 def test_gemm_nt_patch_rowmap():

@@ -37,7 +37,9 @@ def test_layernorm_fwd_bwd(M, D):
     acc = acc0.clone()
     dxb = torch.zeros(M, D, dtype=torch.bfloat16, device='cuda')
     dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
-    ops.layernorm_bwd(dy, x, g, mean, rstd, acc, dx_bf16=dxb, dgamma=dg, dbeta=db)
+    cs = torch.zeros(D, device='cuda')
+    ops.layernorm_bwd(dy, x, g, mean, rstd, acc, dx_bf16=dxb, dgamma=dg, dbeta=db, colsum=cs)
+    _close(cs, acc.sum(0), 2e-5, 'colsum of the updated residual gradient')
     _close(acc - acc0, xr.grad, 2e-5, 'dx')
     _close(dxb, acc, 5e-3, 'dx bf16 copy')
     _close(dg, gr.grad, 2e-5, 'dgamma')
