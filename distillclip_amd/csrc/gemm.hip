@@ -126,11 +126,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     __syncthreads();
     const int cc = (tid & 15) * 8;
     const int col = n0 + cc;
-    if (col >= p.N) return;
+    const bool col_ok = col < p.N;
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-    if (p.bias) {
+    if (p.bias && col_ok) {
         const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     for (int it = 0; it < 8; ++it) {
         const int rl = (tid >> 4) + it * 16;
         const int row = m0 + rl;
-        if (row >= p.M) break;
+        if (row >= p.M || !col_ok) break;
         float v[8];
         {
             const float4 c0 = *(const float4*)(cs + rl * CLD + cc), c1 = *(const float4*)(cs + rl * CLD + cc + 4);
@@ -193,12 +193,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
     }
     if (p.colsum) {
-        // lanes l, l+16, l+32, l+48 of a wave own the same 8 columns
+        // reduce the 16 row-groups through LDS so that each atomic wave-instruction covers 256 contiguous bytes
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = csum[e];
-            x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-            if (lane < 16) unsafeAtomicAdd(p.colsum + col + e, x);
+        for (int e = 0; e < 8; ++e) cs[(tid >> 4) * CLD + cc + e] = csum[e];
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float x = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x += cs[r * CLD + tid];
+            unsafeAtomicAdd(p.colsum + n0 + tid, x);
         }
     }
 }
@@ -444,13 +448,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             }
         }
     }
-    if (p.colsum && col < p.N) {
-        // lanes l and l + 32 of a wave own the same 8 columns
+    if (p.colsum) {
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = csum[e];
-            x += __shfl_xor(x, 32);
-            if (lane < 32) unsafeAtomicAdd(p.colsum + col + e, x);
+        for (int e = 0; e < 8; ++e) cs[(tid >> 5) * CLD2 + cc + e] = csum[e];
+        __syncthreads();
+        if (tid < 256 && n0 + tid < p.N) {
+            float x = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x += cs[r * CLD2 + tid];
+            unsafeAtomicAdd(p.colsum + n0 + tid, x);
         }
     }
 }
