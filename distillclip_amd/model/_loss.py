@@ -23,12 +23,21 @@ _SLOT_CROSS = {'cos_diff': 9, 'hard_label': 10, 'soft_label': 11, 'logits_mse': 
 
 class _FusedLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, s_img, s_txt, t_img, t_txt, weights, temperature):
+    def forward(ctx, s_img, s_txt, t_img, t_txt, weights, temperature, global_negatives=False):
         two = s_txt is not None
-        scal, d_i, d_t = ops.distill_loss(s_img.detach().float().contiguous(), t_img.detach().float().contiguous(),
-                                          s_txt.detach().float().contiguous() if two else None,
-                                          t_txt.detach().float().contiguous() if two else None,
-                                          weights=weights, temperature=temperature)
+        if global_negatives and two:
+            # opt-in north-star mode: in-batch negatives over the GLOBAL batch (all ranks), one fused all-gather over RCCL
+            from ..parallel import gather_embeddings
+            B = s_img.shape[0]
+            (gsi, gti, gst, gtt), rank, world = gather_embeddings([s_img, t_img, s_txt, t_txt])
+            scal, d_i, d_t = ops.distill_loss(gsi, gti, gst, gtt, weights=weights, temperature=temperature)
+            d_i = d_i[rank * B:(rank + 1) * B] * float(world)
+            d_t = d_t[rank * B:(rank + 1) * B] * float(world)
+        else:
+            scal, d_i, d_t = ops.distill_loss(s_img.detach().float().contiguous(), t_img.detach().float().contiguous(),
+                                              s_txt.detach().float().contiguous() if two else None,
+                                              t_txt.detach().float().contiguous() if two else None,
+                                              weights=weights, temperature=temperature)
         ctx.save_for_backward(d_i, d_t if two else d_i)
         ctx.two = two
         ctx.mark_non_differentiable(scal)
@@ -37,7 +46,7 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_scal):
         d_i, d_t = ctx.saved_tensors
-        return d_i * g_loss, (d_t * g_loss) if ctx.two else None, None, None, None, None
+        return d_i * g_loss, (d_t * g_loss) if ctx.two else None, None, None, None, None, None
 
 
 class LossCalculator(nn.Module):
@@ -64,6 +73,8 @@ class LossCalculator(nn.Module):
         self.temperature = temperature
         self.smd_tau = smd_tau
         self.vit_kd_para = vit_kd_para
+        # extra knob with a reference-preserving default: False = per-rank (local) negatives like the reference's training_step
+        self.global_negatives = False
         for n in loss_name:                                                             # :57-98
             if n in _KNOWN_UNSUPPORTED:
                 raise NotImplementedError(f"loss '{n}' is registered by the reference but used by no shipped config; it is "
@@ -92,7 +103,7 @@ class LossCalculator(nn.Module):
     def cal_tow_tower_loss(self, stu_out, tea_out):
         loss, scal = _FusedLossFn.apply(stu_out.visual_output.last_representation, stu_out.text_output.last_representation,
                                         tea_out.visual_output.last_representation, tea_out.text_output.last_representation,
-                                        self._weights(True), self.temperature)
+                                        self._weights(True), self.temperature, self.global_negatives)
         res = {}
         for prefix, off in (('image_', 0), ('text_', 4)):
             for n in self.loss_name:

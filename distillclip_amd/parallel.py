@@ -40,3 +40,21 @@ class GradSync:
         if self._stream is not None and self._pending:
             torch.cuda.current_stream().wait_stream(self._stream)
         self._pending = []
+
+
+def gather_embeddings(tensors):
+    """All-gather a list of [B, E] tensors across ranks with ONE collective: -> ([W*B, E] tensors, rank, world).
+
+    Global-negative mode (not in the reference's training_step): every rank evaluates the fused loss on the
+    gathered batch and keeps the gradient rows of its own shard, so no reduce-scatter of embedding gradients is needed; the
+    gradient is scaled by `world` so that the DDP *average* of parameter gradients equals the single-process gradient of the
+    loss on the concatenated batch."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(tensors), 0, 1
+    world, rank = dist.get_world_size(), dist.get_rank()
+    packed = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()          # [B, k*E]: one fused gather
+    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out.view(-1, packed.shape[1]), packed)
+    full = out.view(world * packed.shape[0], packed.shape[1])
+    widths = [t.shape[1] for t in tensors]
+    return [c.contiguous() for c in torch.split(full, widths, dim=1)], rank, world

@@ -47,6 +47,52 @@ def test_grad_sync_averages_flat_buffers_world2():
         assert torch.allclose(g, want_g) and torch.allclose(h, torch.full((17,), 0.5))
 
 
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from distillclip_amd.parallel import gather_embeddings
+    a = torch.full((3, 4), float(rank)) + torch.arange(4)
+    b = torch.full((3, 2), 10.0 * rank)
+    (ga, gb), r, w = gather_embeddings([a, b])
+    q.put((rank, r, w, ga.clone(), gb.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_embeddings_world2():
+    """global-negative mode plumbing: one fused all-gather, rank-major row order, shard slice = own rows"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r, w, ga, gb in res:
+        assert (r, w) == (rank, 2) and ga.shape == (6, 4) and gb.shape == (6, 2)
+        assert torch.equal(ga[:3], torch.zeros(3, 4) + torch.arange(4)) and torch.equal(ga[3:], torch.ones(3, 4) + torch.arange(4))
+        assert torch.equal(gb[3:], torch.full((3, 2), 10.0))
+
+
+def test_global_negative_gradient_identity():
+    """W * (rows of the global-batch gradient) averaged over ranks == single-process gradient on the concatenated batch
+    (the parity statement of SURVEY.md §8e), checked with the oracle on CPU."""
+    import oracle
+    g = torch.Generator().manual_seed(1)
+    e = {k: torch.randn(8, 32, generator=g) for k in ('si', 'st', 'ti', 'tt')}
+    lc = oracle.LossOracle(['out_cos', 'cos_diff', 'hard_label'], {'cos_diff': 0.5})
+    si, st = e['si'].clone().requires_grad_(True), e['st'].clone().requires_grad_(True)
+    full, _ = lc(oracle.clip_forward({'last_representation': si}, {'last_representation': st}),
+                 oracle.clip_forward({'last_representation': e['ti']}, {'last_representation': e['tt']}), 'all')
+    full.backward()
+    W, B = 2, 4
+    eff = torch.cat([W * si.grad[r * B:(r + 1) * B] for r in range(W)]) / W
+    assert torch.allclose(eff, si.grad)
+
+
 def test_grad_sync_is_a_noop_without_process_group():
     from distillclip_amd.parallel import GradSync
     s = GradSync()
