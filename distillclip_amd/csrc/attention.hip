@@ -187,6 +187,131 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Fused multi-head attention forward (no head mixing: the frozen CLIP teacher, reference _common.py:73-89):
+//   ctx[(b,i), h*HD + d] = sum_j softmax_j(scale * q_i . k_j (+ causal mask)) v_j[d]
+// One wave per (b, h).  Everything is computed transposed so that the query index sits on the lane:
+//   S^T tile = mfma(K frag, Q frag)  -> a lane holds 4 consecutive keys of ONE query: softmax needs 2 cross-lane steps,
+//   P goes to a wave-private LDS tile with 8-byte writes, O^T = V^T P^T (V through LDS + tr16 reads) -> 8-byte stores.
+// Scores and probabilities never touch HBM.
+// ---------------------------------------------------------------------------------------------------------
+struct AttnFused {
+    const bf16_t* qkv; int64_t ldq;      // [B*N, 3*H*HD] : q | k | v
+    bf16_t* ctx; int64_t ldc;
+    int B, H, N, causal;
+    float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
+    constexpr int VROWB = HD * 2 + 32;
+    constexpr int KS = HD / 32, DT = HD / 16, NTM = NMAX / 16, KSM = NMAX / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nprob = p.B * p.H;
+    const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
+    const bool live = blockIdx.x * 4 + wave < nprob;
+    const int b = prob / p.H, h = prob % p.H;
+    const int D = p.H * HD;
+    const int n32 = (p.N + 31) & ~31, nt = (p.N + 15) >> 4, nks = n32 >> 5;
+    const int prowb = n32 * 2 + 16;
+    char* vt = smem + wave * (n32 * VROWB + 16 * prowb);
+    char* pt = vt + n32 * VROWB;
+    const bf16_t* Q = p.qkv + (int64_t)b * p.N * p.ldq + h * HD;
+    const bf16_t* K = Q + D;
+    const bf16_t* V = Q + 2 * D;
+    wave_stage<VROWB>(V, p.ldq, 0, p.N, n32, HD, vt, lane);
+    for (int idx = lane; idx < 16 * prowb / 4; idx += 64) ((unsigned*)pt)[idx] = 0u;
+    const int fr = lane & 15, g = lane >> 4, fk = g * 8;
+    bf16x8 kf[NTM][KS];
+#pragma unroll
+    for (int jt = 0; jt < NTM; ++jt)
+        if (jt < nt) {
+            const int jb = min(jt * 16 + fr, p.N - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[jt][ks] = *(const bf16x8*)(K + (int64_t)jb * p.ldq + ks * 32 + fk);
+        }
+    bf16x8 qf[KS], qn[KS];
+    {
+        const int ia = min(fr, p.N - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Q + (int64_t)ia * p.ldq + ks * 32 + fk);
+    }
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) {
+            const int ia = min((it + 1) * 16 + fr, p.N - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qn[ks] = *(const bf16x8*)(Q + (int64_t)ia * p.ldq + ks * 32 + fk);
+        }
+        const int i = it * 16 + fr;                         // this lane's query
+        // S^T tiles: acc[jt][r] = score(query i, key jt*16 + 4g + r)
+        f32x4 st[NTM];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt) {
+            st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt < nt && (!p.causal || jt <= it)) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[ks], st[jt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + g * 4 + r;
+                    const bool ok = j < p.N && (!p.causal || j <= i);
+                    st[jt][r] = ok ? st[jt][r] * p.scale : -INFINITY;
+                    m = fmaxf(m, st[jt][r]);
+                }
+            } else {
+                st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+            if (jt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = st[jt][r] == -INFINITY ? 0.f : __expf(st[jt][r] - m);
+                    st[jt][r] = e;
+                    sum += e;
+                }
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+            if (jt < nt) {
+                bf16x4 pv = {f2bf(st[jt][0] * inv), f2bf(st[jt][1] * inv), f2bf(st[jt][2] * inv), f2bf(st[jt][3] * inv)};
+                *(bf16x4*)(pt + fr * prowb + (jt * 16 + g * 4) * 2) = pv;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // O^T[d, i] = sum_j V[j, d] P[i, j]
+        f32x4 oc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks)
+            if (ks < nks && (!p.causal || ks * 32 <= it * 16 + 15)) {
+                const bf16x8 pf = *(const bf16x8*)(pt + fr * prowb + (ks * 32 + fk) * 2);
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+                    oc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VROWB>(vt, ks * 32, d * 16, lane), pf, oc[d], 0, 0, 0);
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (live && i < p.N) {
+            bf16_t* o = p.ctx + ((int64_t)b * p.N + i) * p.ldc + h * HD + g * 4;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) *(bf16x4*)(o + d * 16) = bf16x4{f2bf(oc[d][0]), f2bf(oc[d][1]), f2bf(oc[d][2]), f2bf(oc[d][3])};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // TN: C[(b,j), h*HD + d] = alpha * sum_i A[b,h,i,j] * B[(b,i), h*HD + d]   (contraction over query rows)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TN_MAXJ = NMAX / 16;             // 8 output row tiles
@@ -561,6 +686,21 @@ extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C
     if (hd == 32) hipLaunchKernelGGL((attn_tn_kernel<32>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (32 * 2 + 32)), st, p);
     else hipLaunchKernelGGL((attn_tn_kernel<64>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (64 * 2 + 32)), st, p);
     return dclip_check_launch("dclip_attn_tn");
+}
+
+extern "C" int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t hd,
+                                    float scale, int causal, void* stream) {
+    DCLIP_REQUIRE(qkv && ctx && B > 0 && H > 0 && N > 0 && N <= NMAX, "dclip_attn_fused_fwd: bad argument (N <= %d)", NMAX);
+    DCLIP_REQUIRE(hd == 32 || hd == 64, "dclip_attn_fused_fwd: head dim must be 32 or 64 (got %ld)", (long)hd);
+    DCLIP_REQUIRE(ldq % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 8) == 0, "dclip_attn_fused_fwd: misaligned buffers");
+    AttnFused p{(const bf16_t*)qkv, ldq, (bf16_t*)ctx, ldc, (int)B, (int)H, (int)N, causal, scale};
+    const dim3 grid((unsigned)((B * H + 3) / 4));
+    const int n32 = ((int)N + 31) & ~31;
+    const size_t lds = (size_t)4 * (n32 * (hd * 2 + 32) + 16 * (n32 * 2 + 16));
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 32) hipLaunchKernelGGL((attn_fused_fwd_kernel<32>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fused_fwd_kernel<64>), grid, dim3(256), lds, st, p);
+    return dclip_check_launch("dclip_attn_fused_fwd");
 }
 
 #define SM_DISPATCH_H(Hv, NSv, ...)                                               \

@@ -321,9 +321,14 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         float* xout = w.X[ei + 1];
         CK(dclip_layernorm_fwd(xin, D, nullptr, n1w, n1b, s.h1, D, 0, s.mean1, s.rstd1, M, D, 1e-5f, st));
         CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
-        CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
-        CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+        if (!training && !wl) {
+            // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
+            CK(dclip_attn_fused_fwd(s.qkv, 3 * D, s.ctx, D, B, H, N, hd, scale, p.c.causal, st));
+        } else {
+            CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
+            CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
+            CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+        }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
         CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
         CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? DCLIP_ACT_GELU : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));

@@ -136,3 +136,12 @@ def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=N
     lib().dclip_distill_loss(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, ctypes.cast(cfg_arr, ctypes.c_void_p),
                              _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
     return out, d_i, d_t
+
+
+def attn_fused_fwd(qkv, B, N, H, hd, causal=False):
+    """ctx = softmax(q k^T / sqrt(hd) (+ causal mask)) v for plain multi-head attention; qkv: [B*N, 3*H*hd] bf16."""
+    _chk(qkv)
+    D = H * hd
+    ctx = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    lib().dclip_attn_fused_fwd(_p(qkv), qkv.stride(0), _p(ctx), D, B, H, N, hd, hd ** -0.5, 1 if causal else 0, _stream())
+    return ctx

@@ -98,6 +98,10 @@ int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t l
                   int64_t Np, int64_t hd, float alpha, void* stream);
 int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
                   int64_t Np, int64_t hd, float alpha, void* stream);
+/* fused_fwd : ctx = softmax(scale * q k^T (+ causal mask)) v for plain multi-head attention (teacher, _common.py:73-89);
+ *              qkv is the fused [B*N, 3*H*hd] projection ; scores / probabilities never reach HBM. */
+int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t hd,
+                         float scale, int causal, void* stream);
 int dclip_attn_softmax_fwd(const float* S, const float* Wl, const float* Ww, void* P, void* R, int64_t B, int64_t H,
                            int64_t N, int64_t Np, int causal, void* stream);
 int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const float* Wl, const float* Ww, void* dS,

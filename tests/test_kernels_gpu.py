@@ -135,3 +135,20 @@ def test_attention_softmax_stage(B, N, H, mix, causal):
     if mix:
         _close(dww, wwr.grad, 3e-2, 'dWw')
         _close(dwl, wlr.grad, 3e-2, 'dWl')   # bf16 dA / S operands; few positions at the tiny sizes
+
+
+@pytest.mark.parametrize('B,N,H,hd,causal', [(3, 17, 2, 64, False), (2, 13, 2, 64, True), (5, 50, 12, 64, False),
+                                             (3, 77, 8, 64, True), (2, 101, 12, 64, False), (3, 50, 4, 32, False),
+                                             (2, 128, 2, 64, True), (1, 1, 2, 64, False)])
+def test_attention_fused_forward(B, N, H, hd, causal):
+    """fused teacher attention (scores / probabilities never in HBM) vs torch fp32 on the same bf16 q, k, v"""
+    from distillclip_amd import ops
+    D = H * hd
+    qkv = _qkv(B, N, H, hd, 31)
+    q, k, v = (_heads(qkv[:, i * D:(i + 1) * D], B, N, H, hd) for i in range(3))
+    s = q @ k.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        s = s + torch.full((N, N), float('-inf'), device='cuda').triu_(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    got = ops.attn_fused_fwd(qkv, B, N, H, hd, causal)
+    _close(got, ref, 8e-3, 'fused ctx')
