@@ -10,6 +10,7 @@
 //   wcache         : bf16 copies of the GEMM weights (W and, for the student, W^T for dgrad), refreshed by _prepare
 //   workspace      : activations; in training mode everything backward needs stays resident between the two calls
 // No allocation, no synchronisation, no global state: safe to call from the autograd thread and capturable in a hipGraph.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -187,12 +188,22 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w) {
 
 inline const float* PF(const void* const* params, int i) { return (const float*)params[i]; }
 
+// split count of the wgrad contraction: minimise  rounds(tiles*s / 512 resident workgroups) * work per workgroup
+//                                                   + atomic traffic (s * P*Q*4 bytes at ~1.3 TB/s, half hidden)
 inline int wsplits(int64_t M, int64_t P, int64_t Q) {
-    const int64_t tiles = ((P + 127) / 128) * ((Q + 127) / 128);
-    int s = (int)((768 + tiles - 1) / tiles);
-    const int smax = (int)((M + 511) / 512);
-    if (s > smax) s = smax;
-    return s < 1 ? 1 : s;
+    const double tiles = (double)((P + 127) / 128) * (double)((Q + 127) / 128);
+    const int smax = (int)((M + 255) / 256);
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= smax && s <= 64; ++s) {
+        const double blocks = tiles * s;
+        const double rounds = ceil(blocks / 512.0);
+        const double t_mm = rounds * (2.0 * 128 * 128 * ((double)M / s)) / 1.76e12;      // ~900 TF/s shared by 512 workgroups
+        const double t_at = 0.5 * s * (double)P * Q * 4.0 / 1.3e12;
+        const double t = t_mm + t_at + 2e-6;
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
 }
 
 inline int gemm(const void* A, int64_t lda, const void* Bw, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -588,6 +588,105 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// wgrad fast path (M % 64 == 0): same 128x128 output tile, but the k-major [64 x 128] operand tiles are staged by
+// global_load_lds (16 B / lane, 4 rows per wave-instruction) into un-padded 256-byte rows with an XOR swizzle of the
+// 16-byte chunk index, key(row) = 2 * ((row & 3) | ((row >> 3) & 1) << 2), applied on the source address and on the
+// ds_read_b64_tr_b16 address: the 32 lanes of a half-wave (2 groups x 4 rows x 32 B) then cover all 64 banks once.
+// ------------------------------------------------------------------------------------------------------
+constexpr int TNB = TC * 256;                   // 16 KiB operand tile
+
+__device__ __forceinline__ int tn_key(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
+
+__device__ __forceinline__ void tn_stage_glds(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, int cols, char* tile,
+                                              int wave, int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int piece = wave * 4 + s;                 // 16 pieces of 4 rows
+        const int r = piece * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ tn_key(r);         // logical chunk that lands in physical chunk (lane & 15)
+        int col = c0 + lc * 8;
+        col = col < cols ? col : cols - 8;              // column edge: duplicate a valid chunk (those outputs are not stored)
+        const bf16_t* src = G + (int64_t)(m0 + r) * ld + col;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int r0, int x0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = r0 + 8 * g + q;
+    const int chunk = (x0 >> 3) + (pp >> 1);
+    const char* a0 = tile + row * 256 + ((chunk ^ tn_key(row)) << 4) + (pp & 1) * 8;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 256));      // rows + 4: same key
+    return u.v;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+
+    int t = blockIdx.x;
+    const int split = t % p.splits; t /= p.splits;
+    const int tq = t % p.tiles_q, tp = t / p.tiles_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int m_begin = split * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    if (m_begin >= m_end) return;
+    const int nc = (m_end - m_begin) / TC;              // M % 64 == 0 and chunk % 64 == 0
+
+    char* As = smem;
+    char* Bs = smem + 2 * TNB;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    tn_stage_glds(p.A, p.lda, m_begin, p0, p.P, As, wave, lane);
+    tn_stage_glds(p.B, p.ldb, m_begin, q0, p.Q, Bs, wave, lane);
+    for (int ct = 0; ct < nc; ++ct) {
+        __syncthreads();
+        if (ct + 1 < nc) {
+            const int nb = (ct + 1) & 1;
+            tn_stage_glds(p.A, p.lda, m_begin + (ct + 1) * TC, p0, p.P, As + nb * TNB, wave, lane);
+            tn_stage_glds(p.B, p.ldb, m_begin + (ct + 1) * TC, q0, p.Q, Bs + nb * TNB, wave, lane);
+        }
+        const char* a_t = As + (ct & 1) * TNB;
+        const char* b_t = Bs + (ct & 1) * TNB;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tr_frag_swz(a_t, kb * 32, wp * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = tr_frag_swz(b_t, kb * 32, wq * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int colb = q0 + wq * 64 + (lane & 15);
+    const int rowb = p0 + wp * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rowb + i * 16 + r;
+            if (row >= p.P) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = colb + j * 16;
+                if (col < p.Q) unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, acc[i][j][r]);
+            }
+        }
+}
+
 // column sums: grid (ceil(N/256) , row_splits); each thread owns one column, strides rows
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int64_t ld, float* __restrict__ db,
                                                      int M, int N, int rows_per_block) {
@@ -687,8 +786,11 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     p.chunk = chunk;
     p.splits = (int)((M + chunk - 1) / chunk);
     const int grid = p.tiles_p * p.tiles_q * p.splits;
+    static const int tn_mode = [] { const char* e = getenv("DCLIP_TN_GLDS"); return e ? atoi(e) : 1; }();
+    const bool fast = tn_mode != 0 && M % TC == 0 && P >= 8 && Q >= 8;
     TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
+    if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), 4 * TNB, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
     return dclip_check_launch("dclip_gemm_tn_acc");
 }
 

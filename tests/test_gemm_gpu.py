@@ -95,7 +95,8 @@ def test_gemm_nt_rejects_bad_k():
 
 
 @pytest.mark.parametrize('M,P,Q,splits', [(64, 128, 128, 1), (200, 64, 192, 2), (1000, 768, 256, 4), (37, 16, 24, 1),
-                                          (3 * 17, 384, 128, 3)])
+                                          (3 * 17, 384, 128, 3), (1024, 768, 256, 4), (640, 72, 200, 3), (4096, 128, 3072, 7),
+                                          (128, 8, 8, 2)])
 def test_gemm_tn_acc(M, P, Q, splits):
     from distillclip_amd import ops
     a, b = _rand((M, P), 11), _rand((M, Q), 12)
