@@ -121,15 +121,43 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
     }
 }
 
+// Rows whose id is one of the three "hot" ids (padding 0, SOT, EOT in the clip.tokenize layout: every caption has them, so
+// thousands of rows would hammer three table rows with contended atomics) are skipped here and reduced by the kernel below.
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const void* __restrict__ dx,
-                                                            float* __restrict__ dtable, int rows, int D) {
+                                                            float* __restrict__ dtable, int rows, int D, int64_t h0, int64_t h1,
+                                                            int64_t h2) {
     const int64_t total = (int64_t)rows * D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / D), c = (int)(i % D);
+        const int64_t id = ids[r];
+        if (id == h0 || id == h1 || id == h2) continue;
         const float v = IN_F32 ? ((const float*)dx)[i] : bf2f(((const bf16_t*)dx)[i]);
-        unsafeAtomicAdd(dtable + ids[r] * D + c, v);
+        unsafeAtomicAdd(dtable + id * D + c, v);
     }
+}
+
+// dtable[h_k] += sum over rows with ids == h_k of dx[row]   grid (ceil(D/256), row chunks)
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void embed_hot_kernel(const int64_t* __restrict__ ids, const void* __restrict__ dx,
+                                                        float* __restrict__ dtable, int rows, int D, int rows_per_block,
+                                                        int64_t h0, int64_t h1, int64_t h2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    bool s0 = false, s1 = false, s2 = false;
+    for (int r = r0; r < r1; ++r) {
+        const int64_t id = ids[r];                       // wave-uniform
+        if (id != h0 && id != h1 && id != h2) continue;
+        const float v = c < D ? (IN_F32 ? ((const float*)dx)[(int64_t)r * D + c] : bf2f(((const bf16_t*)dx)[(int64_t)r * D + c])) : 0.f;
+        if (id == h0) { a0 += v; s0 = true; }
+        else if (id == h1) { a1 += v; s1 = true; }
+        else { a2 += v; s2 = true; }
+    }
+    if (c >= D) return;
+    if (s0) unsafeAtomicAdd(dtable + h0 * D + c, a0);
+    if (s1) unsafeAtomicAdd(dtable + h1 * D + c, a1);
+    if (s2) unsafeAtomicAdd(dtable + h2 * D + c, a2);
 }
 
 // idx[b] = b*N + argmax_n ids[b,n] (first maximum, like torch.argmax) ; ids == null -> b*N (class-token row)
@@ -238,11 +266,20 @@ extern "C" int dclip_embed_gather(const int64_t* ids, const float* table, const 
 }
 
 extern "C" int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
-                                       void* stream) {
-    DCLIP_REQUIRE(ids && dx && dtable && rows > 0 && D > 0, "dclip_embed_scatter_add: bad argument");
+                                       int64_t vocab, void* stream) {
+    DCLIP_REQUIRE(ids && dx && dtable && rows > 0 && D > 0 && vocab >= 3, "dclip_embed_scatter_add: bad argument");
     const dim3 grid(grid_for(rows * D));
-    if (dx_f32) hipLaunchKernelGGL((embed_scatter_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, dx, dtable, (int)rows, (int)D);
-    else hipLaunchKernelGGL((embed_scatter_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, dx, dtable, (int)rows, (int)D);
+    const int64_t h0 = 0, h1 = vocab - 2, h2 = vocab - 1;       // padding, SOT, EOT (reference data/component/ms_coco.py:37)
+    const int rpb = 128;
+    const dim3 hgrid((unsigned)((D + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+    hipStream_t st = (hipStream_t)stream;
+    if (dx_f32) {
+        hipLaunchKernelGGL((embed_scatter_kernel<true>), grid, dim3(256), 0, st, ids, dx, dtable, (int)rows, (int)D, h0, h1, h2);
+        hipLaunchKernelGGL((embed_hot_kernel<true>), hgrid, dim3(256), 0, st, ids, dx, dtable, (int)rows, (int)D, rpb, h0, h1, h2);
+    } else {
+        hipLaunchKernelGGL((embed_scatter_kernel<false>), grid, dim3(256), 0, st, ids, dx, dtable, (int)rows, (int)D, h0, h1, h2);
+        hipLaunchKernelGGL((embed_hot_kernel<false>), hgrid, dim3(256), 0, st, ids, dx, dtable, (int)rows, (int)D, rpb, h0, h1, h2);
+    }
     return dclip_check_launch("dclip_embed_scatter_add");
 }
 

@@ -434,10 +434,10 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         }
         if (GR(0)) {
             CK(gemm(w.Gb, D, W + p.w_embed_t, D, w.demb, rk, M, rk, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
-            CK(dclip_embed_scatter_add((const int64_t*)input, w.demb, 1, GR(0), M, rk, st));
+            CK(dclip_embed_scatter_add((const int64_t*)input, w.demb, 1, GR(0), M, rk, p.c.vocab, st));
         }
     } else {                     // grads: 0 table, 1 pos
-        if (GR(0)) CK(dclip_embed_scatter_add((const int64_t*)input, w.G, 1, GR(0), M, D, st));
+        if (GR(0)) CK(dclip_embed_scatter_add((const int64_t*)input, w.G, 1, GR(0), M, D, p.c.vocab, st));
         if (GR(1)) {
             CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
             CK(dclip_token_table_bwd(w.tok_sum, GR(1), nullptr, nullptr, N, D, 0, st));

@@ -145,3 +145,11 @@ def attn_fused_fwd(qkv, B, N, H, hd, causal=False):
     ctx = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     lib().dclip_attn_fused_fwd(_p(qkv), qkv.stride(0), _p(ctx), D, B, H, N, hd, hd ** -0.5, 1 if causal else 0, _stream())
     return ctx
+
+
+def embed_scatter_add(ids, dx, dtable):
+    _chk(ids, dx, dtable)
+    rows, D = dx.shape
+    lib().dclip_embed_scatter_add(_p(ids), _p(dx), 1 if dx.dtype == torch.float32 else 0, _p(dtable), rows, D, dtable.shape[0],
+                                  _stream())
+    return dtable

@@ -117,7 +117,8 @@ int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const 
  *                        (_common.py:199-202 ; weight_share_model.py:346-349, :489) ; token_table_bwd is its adjoint given
  *                        tok_sum[n] = sum_b G[b,n,:] from batch_sum_acc.
  * embed_gather         : out[r] = table[ids[r]] + pos[r % N] (text_encoder.py:65-66 ; weight_share_model.py:487-489).
- * embed_scatter_add    : dtable[ids[r]] += dx[r] (f32 atomics).
+ * embed_scatter_add    : dtable[ids[r]] += dx[r] (f32 atomics; rows with the hot ids 0 / vocab-2 / vocab-1 = padding / SOT / EOT
+ *                        of the clip.tokenize layout are reduced per block first instead of contending on three table rows).
  * pick_index           : idx[b] = b*N + argmax_n ids[b,n] (text_encoder.py:86, weight_share_model.py:506); ids NULL: b*N.
  * gather_rows          : out[r] = src[idx[r]] (f32).
  * adamw                : torch.optim.AdamW step on flat f32 buffers (distil_model.py:160-162, dual_distill_model.py:194-196).
@@ -132,7 +133,7 @@ int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_
 int dclip_embed_gather(const int64_t* ids, const float* table, const float* pos, void* out, int out_f32, int64_t rows,
                        int64_t N, int64_t D, void* stream);
 int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
-                            void* stream);
+                            int64_t vocab, void* stream);
 int dclip_pick_index(const int64_t* ids, int32_t* idx, int64_t B, int64_t N, void* stream);
 int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D, void* stream);
 int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

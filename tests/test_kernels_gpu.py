@@ -152,3 +152,16 @@ def test_attention_fused_forward(B, N, H, hd, causal):
     ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
     got = ops.attn_fused_fwd(qkv, B, N, H, hd, causal)
     _close(got, ref, 8e-3, 'fused ctx')
+
+
+def test_embed_scatter_add_with_hot_ids():
+    """token-embedding gradient incl. the contended padding / SOT / EOT rows (clip.tokenize layout)"""
+    from distillclip_amd import ops, synth
+    V, D, B, N = 97, 128, 37, 13
+    ids = torch.from_numpy(synth.captions(3, B, N, V, 3, 9)).cuda().reshape(-1)
+    dx = _randn((B * N, D), 41)
+    tab = torch.ones(V, D, device='cuda')
+    ops.embed_scatter_add(ids, dx, tab)
+    ref = torch.ones(V, D, device='cuda').index_add_(0, ids, dx)
+    _close(tab, ref, 1e-5)
+    assert ref[0].abs().sum() > 0 and ref[V - 1].abs().sum() > 0
