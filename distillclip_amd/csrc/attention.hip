@@ -14,6 +14,7 @@
 //
 // Score-like tensors live as [B, H, N, Np] with Np = round_up(N, 8) (16-byte rows); pad columns are zero.
 // q/k/v/ctx are token-major: row = b*N + n, column = head*hd + d (+ which*D inside the fused qkv buffer).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -106,6 +107,22 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int x0, int 
     u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
     u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
     return u.v;
+}
+
+// B fragment of v_mfma_f32_32x32x16_bf16 from a k-major LDS tile (rows = contraction index, 32 columns from x0,
+// 16 rows from r0): lane (col = l & 31, k = 8*(l >> 5) + e).  Each 16-lane group does two ds_read_b64_tr_b16.
+template <int ROWB>
+__device__ __forceinline__ bf16x8 tr_frag32(const char* tile, int r0, int x0, int lane) {
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const char* a0 = tile + (r0 + 8 * (g4 >> 1) + q) * ROWB + (x0 + 16 * (g4 & 1) + 4 * pp) * 2;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
+    return u.v;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
 // copy `rows` x `cols` bf16 (cols % 8 == 0) from global (row stride ld) into a wave-private LDS tile (row stride ROWB
@@ -450,6 +467,131 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(SoftmaxFwd p) {
     }
 }
 
+// Head-mixing softmax forward on MFMA (one wave per (b, query row), tiles [32 heads][COLS keys] in wave-private LDS):
+//   A_g = sum_h Wl[g,h] S_h     3 MFMAs per step with split-bf16 operands (Wl_hi S_hi + Wl_hi S_lo + Wl_lo S_hi): ~16 mantissa
+//                               bits on the pre-softmax scores instead of 8
+//   e   = exp(A - rowmax)       ONE cross-lane max per query row (shared by the heads; softmax is shift-invariant per head)
+//   sum_g = sum_j e[g,j]        MFMA of the e tile against a ones operand -> lands in accumulator layout (row g)
+//   P = e / sum (saved for backward) ; R_g = sum_h Ww[g,h] P_h (MFMA) ; P and R leave through LDS as 16-byte rows
+template <int H, int NS>
+__global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p) {
+    constexpr int COLS = 64 * NS, ROWB = COLS * 2 + 16, NCT = COLS / 32, TILE = 32 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* tH = smem + wave * 3 * TILE;          // S_hi, later R
+    char* tL = tH + TILE;                       // S_lo
+    char* tP = tL + TILE;                       // e, then P
+    for (int idx = lane; idx < 3 * TILE / 16; idx += 64) ((u32x4*)tH)[idx] = u32x4{0u, 0u, 0u, 0u};
+    const int hh = lane >> 5, c = lane & 31;
+    bf16x8 aLh[2], aLl[2], aW[2], ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int h = 16 * s + 8 * hh + e;                                   // A[g = c][k = h]
+            const float wl = (h < H && c < H) ? p.Wl[c * H + h] : 0.f;
+            const bf16_t hi = f2bf(wl);
+            aLh[s][e] = hi;
+            aLl[s][e] = f2bf(wl - bf2f(hi));
+            aW[s][e] = f2bf((h < H && c < H) ? p.Ww[c * H + h] : 0.f);
+        }
+    const int64_t hs = (int64_t)p.N * p.Np;
+    const int rows = p.B * p.N;
+    const int nchunk = p.Np >> 3, total = H * nchunk;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int b = row / p.N, i = row % p.N;
+        const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < total; idx += 64) {
+            const int h = idx / nchunk, ck = idx - h * nchunk;
+            const int64_t src = base + h * hs + ck * 8;
+            const float4 s0 = *(const float4*)(p.S + src), s1 = *(const float4*)(p.S + src + 4);
+            const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = f2bf(v[e]); lo[e] = f2bf(v[e] - bf2f(hi[e])); }
+            *(bf16x8*)(tH + h * ROWB + ck * 16) = hi;
+            *(bf16x8*)(tL + h * ROWB + ck * 16) = lo;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        f32x16 am[NCT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            am[ct] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 bh = tr_frag32<ROWB>(tH, 16 * s, 32 * ct, lane), bl = tr_frag32<ROWB>(tL, 16 * s, 32 * ct, lane);
+                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLh[s], bh, am[ct], 0, 0, 0);
+                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLh[s], bl, am[ct], 0, 0, 0);
+                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLl[s], bh, am[ct], 0, 0, 0);
+            }
+            const bool jok = 32 * ct + c < p.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (jok && g < H) m = fmaxf(m, am[ct][r]);
+            }
+        }
+        m = wave_max(m);
+        // e = exp(A - m) as bf16 rows [g][j] in LDS (pad keys / pad heads stay zero)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const bool jok = 32 * ct + c < p.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float e = (jok && g < H) ? __expf(am[ct][r] - m) : 0.f;
+                am[ct][r] = e;
+                *(bf16_t*)(tP + g * ROWB + (32 * ct + c) * 2) = f2bf(e);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // row sums on the matrix pipe: sum_g = sum_j e[g, j] * 1  (accumulator layout: row g in the registers)
+        f32x16 rs = {0};
+#pragma unroll
+        for (int ks = 0; ks < COLS / 16; ++ks)
+            rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tP + c * ROWB + (ks * 16 + hh * 8) * 2), ones, rs, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pv = g < H ? am[ct][r] / rs[r] : 0.f;
+                *(bf16_t*)(tP + g * ROWB + (32 * ct + c) * 2) = f2bf(pv);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // R = Ww P, written over the (dead) S_hi tile as bf16 rows
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x16 rr = {0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aW[s], tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), rr, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                *(bf16_t*)(tH + g * ROWB + (32 * ct + c) * 2) = f2bf(rr[r]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < total; idx += 64) {
+            const int h = idx / nchunk, ck = idx - h * nchunk;
+            const int64_t dst = base + h * hs + ck * 8;
+            if (p.P) *(u32x4*)(p.P + dst) = *(const u32x4*)(tP + h * ROWB + ck * 16);
+            *(u32x4*)(p.R + dst) = *(const u32x4*)(tH + h * ROWB + ck * 16);
+        }
+    }
+}
+
 // backward of the stage above.  dP = Ww^T dR ; dA = P o (dP - sum_j P dP) ; dS = Wl^T dA
 // dWw[g,h] += sum dR_g P_h ; dWl[g,h] += sum dA_g S_h     (32x32x16 MFMA over the key axis, per-wave accumulators)
 struct SoftmaxBwd {
@@ -463,22 +605,6 @@ struct SoftmaxBwd {
     float* dWw;
     int B, N, Np;
 };
-
-// B fragment of v_mfma_f32_32x32x16_bf16 from a k-major LDS tile (rows = contraction index, 32 columns from x0,
-// 16 rows from r0): lane (col = l & 31, k = 8*(l >> 5) + e).  Each 16-lane group does two ds_read_b64_tr_b16.
-template <int ROWB>
-__device__ __forceinline__ bf16x8 tr_frag32(const char* tile, int r0, int x0, int lane) {
-    const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const char* a0 = tile + (r0 + 8 * (g4 >> 1) + q) * ROWB + (x0 + 16 * (g4 & 1) + 4 * pp) * 2;
-    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
-    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
-    return u.v;
-}
-
-__device__ __forceinline__ float lane_bcast(float v, int src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
 
 // Head-mixing softmax backward, everything matrix-shaped on v_mfma_f32_32x32x16_bf16 (one wave per (b, query row)):
 //   Cw[g,h] = sum_j dR[g,j] P[h,j]                (this row's dW_w contribution; also gives the softmax row sums:)
@@ -721,10 +847,18 @@ extern "C" int dclip_attn_softmax_fwd(const float* S, const float* Wl, const flo
     DCLIP_REQUIRE(S && R && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_softmax_fwd: bad argument");
     DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_fwd: conv_l and conv_w come together");
     SoftmaxFwd p{S, Wl, Ww, (bf16_t*)P, (bf16_t*)R, (int)B, (int)N, (int)Np, causal};
-    const dim3 grid((unsigned)((B * N + 3) / 4));
     const int ns = N > 64 ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
-    SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_fwd_kernel<HH, NSS>), grid, dim3(256), 0, st, p));
+    static const int mfma_mode = [] { const char* e = getenv("DCLIP_SOFTMAX_MFMA"); return e ? atoi(e) : 1; }();
+    if (Wl && !causal && mfma_mode && H > 12) {     // H <= 12: the 144-FMA register mix is faster than 32-row MFMA tiles (measured)
+        int blocks = (int)((B * N + 3) / 4);
+        if (blocks > 512) blocks = 512;              // persistent waves: constant fragments / LDS zero-fill amortised over rows
+        const size_t lds = (size_t)4 * 3 * 32 * (64 * ns * 2 + 16);
+        SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_fwd_mix_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
+    } else {
+        const dim3 grid((unsigned)((B * N + 3) / 4));
+        SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_fwd_kernel<HH, NSS>), grid, dim3(256), 0, st, p));
+    }
     return dclip_check_launch("dclip_attn_softmax_fwd");
 }
 
