@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
     char* tP = tL + TILE;                       // e, then P
     for (int idx = lane; idx < 3 * TILE / 16; idx += 64) ((u32x4*)tH)[idx] = u32x4{0u, 0u, 0u, 0u};
     const int hh = lane >> 5, c = lane & 31;
-    bf16x8 aLh[2], aLl[2], aW[2], ones;
+    bf16x8 aLh[2], aLl[2], aWh[2], aWl2[2], ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
 #pragma unroll
@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
             const bf16_t hi = f2bf(wl);
             aLh[s][e] = hi;
             aLl[s][e] = f2bf(wl - bf2f(hi));
-            aW[s][e] = f2bf((h < H && c < H) ? p.Ww[c * H + h] : 0.f);
+            const float ww = (h < H && c < H) ? p.Ww[c * H + h] : 0.f;
+            const bf16_t whi = f2bf(ww);
+            aWh[s][e] = whi;
+            aWl2[s][e] = f2bf(ww - bf2f(whi));
         }
     const int64_t hs = (int64_t)p.N * p.Np;
     const int rows = p.B * p.N;
@@ -564,7 +567,9 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
             for (int r = 0; r < 16; ++r) {
                 const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const float pv = g < H ? am[ct][r] / rs[r] : 0.f;
-                *(bf16_t*)(tP + g * ROWB + (32 * ct + c) * 2) = f2bf(pv);
+                const bf16_t phi = f2bf(pv);
+                *(bf16_t*)(tP + g * ROWB + (32 * ct + c) * 2) = phi;                       // saved P (bf16) = the hi part
+                *(bf16_t*)(tL + g * ROWB + (32 * ct + c) * 2) = f2bf(pv - bf2f(phi));    // lo part, over the dead S_lo tile
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -573,8 +578,12 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
         for (int ct = 0; ct < NCT; ++ct) {
             f32x16 rr = {0};
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aW[s], tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), rr, 0, 0, 0);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 ph = tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), pl = tr_frag32<ROWB>(tL, 16 * s, 32 * ct, lane);
+                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWh[s], ph, rr, 0, 0, 0);
+                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWh[s], pl, rr, 0, 0, 0);
+                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl2[s], ph, rr, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
