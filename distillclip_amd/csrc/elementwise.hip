@@ -199,6 +199,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src into colsum (row length D)
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, bf16_t* __restrict__ dst_bf16,
+                                                   int64_t n, float* __restrict__ colsum, int D) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        const float4 s = *(const float4*)(src + i);
+        float4 d = *(const float4*)(dst + i);
+        d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+        *(float4*)(dst + i) = d;
+        if (dst_bf16) *(bf16x4*)(dst_bf16 + i) = bf16x4{f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
+        if (colsum) {
+            const int c = (int)(i % D);
+            unsafeAtomicAdd(colsum + c, s.x); unsafeAtomicAdd(colsum + c + 1, s.y);
+            unsafeAtomicAdd(colsum + c + 2, s.z); unsafeAtomicAdd(colsum + c + 3, s.w);
+        }
+    }
+}
+
 inline int grid_for(int64_t work, int per_block = 256, int cap = 2048 * 4) {
     int64_t g = (work + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -304,4 +321,10 @@ extern "C" int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2);
     return dclip_check_launch("dclip_adamw");
+}
+
+extern "C" int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream) {
+    DCLIP_REQUIRE(dst && src && n > 0 && n % 4 == 0 && D > 0 && D % 4 == 0, "dclip_axpy_f32: bad argument");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, dst, src, (bf16_t*)dst_bf16, n, colsum_acc, (int)D);
+    return dclip_check_launch("dclip_axpy_f32");
 }

@@ -279,7 +279,7 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
 
 extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
                                      const void* wcache, void* workspace, size_t ws_bytes, int training,
-                                     float* last_representation, void* st) {
+                                     float* last_representation, float* const* rep_out, float* emb_out, void* st) {
     DCLIP_REQUIRE(e && input && params && wcache && workspace && last_representation, "dclip_encoder_forward: null argument");
     DCLIP_REQUIRE(B > 0, "dclip_encoder_forward: empty batch");
     const Plan& p = e->p;
@@ -310,6 +310,16 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         CK(gemm(w.patches, p.c.embed_rank, W + p.w_embed, p.c.embed_rank, w.X[0], D, M, D, p.c.embed_rank, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
     } else {                     // params: 0 table [V,D], 1 pos [N,D]
         CK(dclip_embed_gather((const int64_t*)input, PF(params, 0), PF(params, 1), w.X[0], 1, M, N, D, st));
+    }
+
+    // optional export of the post-positional-embedding tokens (reference ControlOutput.need_emb: _common.py:204-206 captures
+    // them BEFORE ln_pre; text_encoder.py:66-67 ; weight_share_model.py:350,490)
+    if (emb_out) {
+        const float* src = (!p.student && p.image) ? w.x0 : w.X[0];
+        if (hipMemcpyAsync(emb_out, src, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {
+            dclip_set_error("dclip_encoder_forward: embedding export failed");
+            return DCLIP_ELAUNCH;
+        }
     }
 
     // ---- blocks --------------------------------------------------------------------------------------------
@@ -344,6 +354,12 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
         CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? DCLIP_ACT_GELU : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
         CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
+        // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
+        if (rep_out && rep_out[ei] &&
+            hipMemcpyAsync(rep_out[ei], xout, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {
+            dclip_set_error("dclip_encoder_forward: hidden-state export failed");
+            return DCLIP_ELAUNCH;
+        }
     }
 
     // ---- final norm + projection on the picked token only (class token / EOT = argmax of the ids) ----------------
@@ -356,7 +372,7 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
 
 extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
                                       void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
-                                      const float* d_last_representation, void* st) {
+                                      const float* d_last_representation, const float* const* d_rep, const float* d_emb, void* st) {
     DCLIP_REQUIRE(e && input && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
     const Plan& p = e->p;
     DCLIP_REQUIRE(p.student, "dclip_encoder_backward: only the student tower trains");
@@ -393,6 +409,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         const SB sb = sblock(p, l); const SR sr = srepeat(p, l, r);
         const float *wl = nullptr, *ww = nullptr;
         if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
+        // gradient arriving directly at this execution's output (feature-MSE terms): G += d_rep[ei], refresh the bf16 copy
+        if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], w.Gb, M * D, GR(sb.f2b), D, st));
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         if (GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.Gb, D, s.u, F, GR(sb.f2w), F, M, D, F, wsplits(M, D, F), st));
         CK(dclip_gemm_nt(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_DGELU, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
@@ -418,6 +436,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     }
 
     // ---- embedding ---------------------------------------------------------------------------------------------
+    if (d_emb) CK(dclip_axpy_f32(w.G, d_emb, w.Gb, M * D, nullptr, D, st));
     if (hipMemsetAsync(w.tok_sum, 0, (size_t)N * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
     if (p.image) {           // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
         if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), st));

@@ -15,8 +15,9 @@ from .. import ops
 IMAGE_TEXT_LOSS = ['hard_label', 'soft_label', 'logits_mse', 'fine_grain', 'cos_diff']     # reference _loss.py:14
 _TOWER_FUSED = ('out_l1', 'out_cos', 'out_kl', 'out_ce')
 _CROSS_FUSED = ('cos_diff', 'hard_label', 'soft_label', 'logits_mse')
-_KNOWN_UNSUPPORTED = ('embedding_mse', 'attention_score_mse', 'attention_probs_mse', 'hidden_rep_mse',
-                      'attention_probs_kl', 'last_value_map_kl', 'vit_kd', 'fine_grain', 'smd')
+_FEATURE = ('hidden_rep_mse', 'embedding_mse')
+_KNOWN_UNSUPPORTED = ('attention_score_mse', 'attention_probs_mse', 'attention_probs_kl', 'last_value_map_kl', 'vit_kd',
+                      'fine_grain', 'smd')
 _SLOT_TOWER = {'out_l1': 1, 'out_cos': 2, 'out_kl': 3, 'out_ce': 4}
 _SLOT_CROSS = {'cos_diff': 9, 'hard_label': 10, 'soft_label': 11, 'logits_mse': 12}
 
@@ -49,6 +50,25 @@ class _FusedLossFn(torch.autograd.Function):
         return d_i * g_loss, (d_t * g_loss) if ctx.two else None, None, None, None, None, None
 
 
+class _FeatureMSEFn(torch.autograd.Function):
+    """mean((s - t)^2) with the gradient 2 (s - t) / n, both by dclip_feature_mse (hidden_mse.py / embed_mse.py)."""
+
+    @staticmethod
+    def forward(ctx, s, t):
+        s = s.contiguous().float()
+        t = t.detach().contiguous().float()
+        if s.shape != t.shape:
+            raise RuntimeError(f'The size of tensor a {tuple(s.shape)} must match the size of tensor b {tuple(t.shape)}')
+        val, ds = ops.feature_mse(s.detach(), t)
+        ctx.save_for_backward(ds)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return ds * g, None
+
+
 class LossCalculator(nn.Module):
     def __init__(self, loss_name: List, loss_scale: dict = None, temperature=None, percent=None, smd_tau: float = 0.04,
                  vit_kd_para: Dict = None):
@@ -79,11 +99,28 @@ class LossCalculator(nn.Module):
             if n in _KNOWN_UNSUPPORTED:
                 raise NotImplementedError(f"loss '{n}' is registered by the reference but used by no shipped config; it is "
                                           f'outside the HIP hot path (SURVEY.md §2.1)')
-            if n not in _TOWER_FUSED and n not in _CROSS_FUSED:
+            if n not in _TOWER_FUSED and n not in _CROSS_FUSED and n not in _FEATURE:
                 raise ValueError('Invalid Loss Type!')
 
     def get_control_output(self):
-        return ControlOutput()      # reference :100-116: none of the fused terms needs extra activations
+        # reference :100-116
+        return ControlOutput(need_emb='embedding_mse' in self.loss_name, need_rep='hidden_rep_mse' in self.loss_name)
+
+    def _feature_terms(self, stu, tea):
+        """-> (weighted sum, {name: scaled value}) of the hidden-state / embedding MSE terms of one tower"""
+        total, res = 0, {}
+        for n in self.loss_name:
+            if n == 'hidden_rep_mse':
+                # reference hidden_mse.py:9-17: pairs by zip(), divided by the number of STUDENT hidden states
+                val = sum(_FeatureMSEFn.apply(s, t) for s, t in zip(stu.representations, tea.representations))
+                val = val / max(len(stu.representations), 1)
+            elif n == 'embedding_mse':
+                val = _FeatureMSEFn.apply(stu.embedding, tea.embedding)
+            else:
+                continue
+            res[n] = val * self.loss_scale[n]
+            total = total + res[n] * self.percent[n]
+        return total, res
 
     def set_percent(self, new_percent):
         self.percent = new_percent
@@ -105,10 +142,14 @@ class LossCalculator(nn.Module):
                                         tea_out.visual_output.last_representation, tea_out.text_output.last_representation,
                                         self._weights(True), self.temperature, self.global_negatives)
         res = {}
-        for prefix, off in (('image_', 0), ('text_', 4)):
+        for prefix, off, so, to in (('image_', 0, stu_out.visual_output, tea_out.visual_output),
+                                    ('text_', 4, stu_out.text_output, tea_out.text_output)):
             for n in self.loss_name:
                 if n in _TOWER_FUSED:
                     res[prefix + n] = scal[_SLOT_TOWER[n] + off] * self.loss_scale[n]
+            ft, fres = self._feature_terms(so, to)
+            loss = loss + 0.5 * ft                                       # reference :148: 0.5 * (image_loss + text_loss)
+            res.update({prefix + k: v for k, v in fres.items()})
         for n in self.loss_name:
             if n in _CROSS_FUSED:
                 res[n] = scal[_SLOT_CROSS[n]] * self.loss_scale[n]
@@ -118,7 +159,9 @@ class LossCalculator(nn.Module):
         loss, scal = _FusedLossFn.apply(stu_out.last_representation, None, tea_out.last_representation, None,
                                         self._weights(False), self.temperature)
         res = {n: scal[_SLOT_TOWER[n]] * self.loss_scale[n] for n in self.loss_name if n in _TOWER_FUSED}
-        return loss, res
+        ft, fres = self._feature_terms(stu_out, tea_out)
+        res.update(fres)
+        return loss + ft, res
 
     def forward(self, stu_out, tea_out, model_type: str):
         if model_type == 'all':

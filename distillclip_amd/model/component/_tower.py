@@ -120,7 +120,8 @@ class HipTower:
         self.wcache_dirty = False
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def forward(self, x, training):
+    def forward(self, x, training, need_rep=False, need_emb=False, rep_layers=None):
+        """-> (last_representation [B,E], input as passed to C, hidden states list, embedding or None)"""
         if not x.is_cuda:
             raise RuntimeError('distillclip_amd towers need CUDA(HIP) inputs; there is no CPU fallback')
         expect = torch.float32 if self.cfg.modality == 0 else torch.int64
@@ -134,13 +135,25 @@ class HipTower:
         self._ensure_workspace(B, training, x.device)
         out = torch.empty((B, self.cfg.out_dim), dtype=torch.float32, device=x.device)
         ps = self._params()
+        nex = self.cfg.layers * self.cfg.repeats
+        N, D = self.cfg.tokens, self.cfg.width
+        reps, rep_arr = [], None
+        if need_rep:
+            want = range(nex) if rep_layers is None else [i for i in rep_layers if 0 <= i < nex]
+            slots = [None] * nex
+            for i in want:
+                slots[i] = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+            reps = [slots[i] for i in want]
+            rep_arr = _ptr_array(slots)
+        emb = torch.empty((B, N, D), dtype=torch.float32, device=x.device) if need_emb else None
         lib().dclip_encoder_forward(self._handle, x.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
                                     self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
-                                    out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                    out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
         self._saved_batch = B if training else None
-        return out, x
+        return out, x, reps, emb
 
-    def backward(self, x, d_out):
+    def backward(self, x, d_out, d_reps=None, d_emb=None):
         B = x.shape[0]
         if self._saved_batch != B:
             raise RuntimeError('backward without a matching training-mode forward (activations are kept in the workspace '
@@ -148,10 +161,15 @@ class HipTower:
         self.attach_grads()
         ps = self._params()
         gs = [None if (p is None or not p.requires_grad) else p.grad for p in ps]
+        if d_out is None:
+            d_out = torch.zeros((B, self.cfg.out_dim), dtype=torch.float32, device=x.device)
         d_out = d_out.contiguous().float()
+        keep = [None if g is None else g.contiguous().float() for g in (d_reps or [])]
+        d_emb = None if d_emb is None else d_emb.contiguous().float()
         lib().dclip_encoder_backward(self._handle, x.data_ptr(), B, _ptr_array(ps), _ptr_array(gs), self.wcache.data_ptr(),
                                      self.workspace.data_ptr(), self.workspace.numel(), d_out.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     _ptr_array(keep) if any(g is not None for g in keep) else None,
+                                     None if d_emb is None else d_emb.data_ptr(), torch.cuda.current_stream().cuda_stream)
         self._saved_batch = None
 
 
@@ -159,20 +177,27 @@ class _TowerFn(torch.autograd.Function):
     """autograd edge of a student tower: forward / backward are one C-ABI call each."""
 
     @staticmethod
-    def forward(ctx, anchor, x, tower):
-        out, xin = tower.forward(x, training=True)
+    def forward(ctx, anchor, x, tower, need_rep, need_emb):
+        out, xin, reps, emb = tower.forward(x, training=True, need_rep=need_rep, need_emb=need_emb)
         ctx.tower = tower
         ctx.x = xin
-        return out
+        ctx.n_rep = len(reps)
+        ctx.has_emb = emb is not None
+        return (out,) + tuple(reps) + ((emb,) if emb is not None else ())
 
     @staticmethod
-    def backward(ctx, d_out):
-        ctx.tower.backward(ctx.x, d_out)
-        return None, None, None
+    def backward(ctx, d_out, *rest):
+        d_reps = list(rest[:ctx.n_rep])
+        d_emb = rest[ctx.n_rep] if ctx.has_emb else None
+        ctx.tower.backward(ctx.x, d_out, d_reps, d_emb)
+        return None, None, None, None, None
 
 
-def run_tower(tower, x, anchor):
+def run_tower(tower, x, anchor, need_rep=False, need_emb=False):
+    """-> (last_representation, [hidden state per block execution], embedding or None)"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in tower.module.parameters()):
-        return _TowerFn.apply(anchor, x, tower)
-    out, _ = tower.forward(x, training=False)
-    return out
+        res = _TowerFn.apply(anchor, x, tower, need_rep, need_emb)
+        nex = tower.cfg.layers * tower.cfg.repeats if need_rep else 0
+        return res[0], list(res[1:1 + nex]), (res[1 + nex] if need_emb else None)
+    out, _, reps, emb = tower.forward(x, training=False, need_rep=need_rep, need_emb=need_emb)
+    return out, reps, emb

@@ -115,12 +115,13 @@ class ImageEncoder(nn.Module):
         return self.visual.proj
 
     def encode_image(self, image, control_output: ControlOutput = None):
-        co = control_output
-        if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map or co.need_rep or co.need_emb):
-            raise NotImplementedError('teacher hidden states / attention maps are not exported by the HIP tower yet')
-        with torch.no_grad():
-            out, _ = self._tower.forward(image, training=False)
-        return VisionTransformerOutput(last_representation=out)
+        co = control_output or ControlOutput()
+        if co.need_attn_score or co.need_attn_prob or co.need_value_map:
+            raise NotImplementedError('teacher attention maps are not exported by the HIP tower (SURVEY.md §2.1)')
+        with torch.no_grad():   # hidden states only for `need_layers` (reference _common.py:154-158)
+            out, _, reps, emb = self._tower.forward(image, training=False, need_rep=co.need_rep, need_emb=co.need_emb,
+                                                    rep_layers=list(self.need_layers) if self.need_layers is not None else None)
+        return VisionTransformerOutput(last_representation=out, representations=reps, embedding=emb)
 
     def forward(self, image, control_output: ControlOutput = None):
         return self.encode_image(image, control_output)

@@ -144,10 +144,9 @@ class _StudentBase(nn.Module):
         return self.hyper
 
     def _check_control(self, co: Optional[ControlOutput]):
-        if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map or co.need_rep or co.need_emb):
-            raise NotImplementedError('the HIP towers keep attention internals / hidden states on chip; loss terms that need '
-                                      'them (attention_*, last_value_map_kl, hidden_rep_mse, embedding_mse, vit_kd) are not '
-                                      'wired through this boundary yet (SURVEY.md §2.1)')
+        if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map):
+            raise NotImplementedError('the HIP towers keep attention scores / probabilities / value maps on chip; the loss terms '
+                                      'that need them (attention_*, last_value_map_kl) are outside the hot path (SURVEY.md §2.1)')
 
 
 class RepeatVisionTransformer(_StudentBase):
@@ -194,8 +193,10 @@ class RepeatVisionTransformer(_StudentBase):
 
     def forward_features(self, x, control_output: ControlOutput = None):
         self._check_control(control_output)
-        rep = run_tower(self._tower, x, self._anchor_for(x.device))
-        return VisionTransformerOutput(last_representation=rep)
+        co = control_output or ControlOutput()
+        rep, hidden, emb = run_tower(self._tower, x, self._anchor_for(x.device), co.need_rep, co.need_emb)
+        # like the reference, EVERY block execution contributes a hidden state (weight_share_model.py:211, :356-357)
+        return VisionTransformerOutput(last_representation=rep, representations=hidden, embedding=emb)
 
     def forward(self, x, control_output: ControlOutput = None):
         return self.forward_features(x, control_output)
@@ -254,8 +255,9 @@ class RepeatTextTransformer(_StudentBase):
 
     def forward_features(self, text, control_output: ControlOutput = None):
         self._check_control(control_output)
-        rep = run_tower(self._tower, text, self._anchor_for(text.device))
-        return TextTransformerOutput(last_representation=rep)
+        co = control_output or ControlOutput()
+        rep, hidden, emb = run_tower(self._tower, text, self._anchor_for(text.device), co.need_rep, co.need_emb)
+        return TextTransformerOutput(last_representation=rep, representations=hidden, embedding=emb)
 
     def forward(self, x, control_output: ControlOutput = None):
         return self.forward_features(x, control_output)

@@ -92,7 +92,9 @@ class DualDistillModel(nn.Module):
                     else:
                         with torch.no_grad():
                             o = enc(x, co)
-                o.last_representation.record_stream(main)
+                for t_ in [o.last_representation, o.embedding] + list(o.representations or []):
+                    if t_ is not None:
+                        t_.record_stream(main)
                 outs.append(o)
             for st in self._streams:
                 main.wait_stream(st)

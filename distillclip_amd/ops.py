@@ -153,3 +153,13 @@ def embed_scatter_add(ids, dx, dtable):
     lib().dclip_embed_scatter_add(_p(ids), _p(dx), 1 if dx.dtype == torch.float32 else 0, _p(dtable), rows, D, dtable.shape[0],
                                   _stream())
     return dtable
+
+
+def feature_mse(s, t, coef=1.0):
+    """-> (mean((s - t)^2) * coef as a 0-d tensor, d/ds of it)"""
+    _chk(s, t)
+    assert s.dtype == torch.float32 and t.dtype == torch.float32 and s.numel() == t.numel() and s.numel() % 4 == 0
+    val = torch.zeros(1, dtype=torch.float32, device=s.device)
+    ds = torch.zeros_like(s)
+    lib().dclip_feature_mse(_p(s), _p(t), s.numel(), float(coef), _p(val), _p(ds), _stream())
+    return val[0], ds

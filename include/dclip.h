@@ -124,6 +124,8 @@ int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const 
  * adamw                : torch.optim.AdamW step on flat f32 buffers (distil_model.py:160-162, dual_distill_model.py:194-196).
  */
 int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src (row length D) */
+int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream);
 int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream);
 int dclip_im2row(const float* img, void* rows, int64_t B, int64_t C, int64_t res, int64_t patch, int cls_rows, void* stream);
 int dclip_token_table(const float* pos, const float* cls, const float* bias, float* out, int64_t ntok, int64_t D, void* stream);
@@ -209,13 +211,16 @@ size_t dclip_encoder_workspace_bytes(const dclip_encoder* enc, int64_t B, int tr
 /* refresh the bf16 GEMM-weight cache from the f32 parameters (student: every step; teacher: once) */
 int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, void* wcache, void* stream);
 /* input: image f32 [B,C,res,res] or token ids i64 [B,N].  last_representation: f32 [B,E] (class token / EOT row).
- * training = 1 keeps every activation backward needs inside `workspace` (student only). */
+ * training = 1 keeps every activation backward needs inside `workspace` (student only).
+ * rep_out (nullable array of layers*repeats nullable f32 [B*N, D] pointers) / emb_out (nullable f32 [B*N, D]) receive the hidden
+ * state after each block execution and the post-positional-embedding tokens (ControlOutput.need_rep / need_emb of the
+ * reference, _loss.py:100-116); d_rep / d_emb are the matching gradients, added to the residual-stream gradient in backward. */
 int dclip_encoder_forward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                           const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
-                          void* stream);
+                          float* const* rep_out, float* emb_out, void* stream);
 int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
-                           const float* d_last_representation, void* stream);
+                           const float* d_last_representation, const float* const* d_rep, const float* d_emb, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Launch trace (profiling only; process-global): between begin and end every GEMM / LayerNorm-forward / loss call is

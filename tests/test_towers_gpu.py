@@ -171,6 +171,45 @@ def test_tiny_one_tower_text_compressed(tiny):
     _grad_check(s, tiny, 'txtc.s_txt.grad.', L1_TOL, 2 * L1_TOL)
 
 
+def test_tiny_one_tower_image_feature_mse(tiny):
+    """hidden_rep_mse + embedding_mse (SURVEY.md §2.1 tier 2): hidden states / embeddings exported by both towers, the
+    gradients re-enter the student's backward at every block execution.  Golden = the reference run `img1`."""
+    from distillclip_amd.model import LossCalculator
+    from distillclip_amd.model.component import ImageEncoder
+    c = TINY
+    s_img, _, _, _ = _tiny_modules()
+    t_img = ImageEncoder(False, dict(input_resolution=c['res'], patch_size=c['patch'], width=128, layers=2, heads=2,
+                                     output_dim=c['out_dim'], need_layers=[0, 1]))
+    t_img.load_state_dict(T(synth.teacher_image_state(c['seed'], 128, 2, c['patch'], c['res'], c['out_dim'])))
+    t_img = t_img.cuda()
+    lc = LossCalculator(['out_l1', 'out_cos', 'hidden_rep_mse', 'embedding_mse'])
+    co = lc.get_control_output()
+    assert co.need_rep and co.need_emb
+    image = torch.from_numpy(tiny['image']).cuda()
+    so, to = s_img(image, co), t_img(image, co)
+    assert len(so.representations) == 4 and len(to.representations) == 2          # student: every execution; teacher: need_layers
+    for i in range(4):
+        assert rel_l2(so.representations[i], tiny[f's_img.rep{i}']) < 2e-2
+    for i in range(2):
+        assert rel_l2(to.representations[i], tiny[f't_img.rep{i}']) < 2e-2
+    assert rel_l2(so.embedding, tiny['s_img.embedding']) < 1e-2 and rel_l2(to.embedding, tiny['t_img.embedding']) < 1e-2
+    loss, res = lc(so, to, 'image')
+    assert abs(loss.item() - float(tiny['img1.loss'])) <= 2e-2 * abs(float(tiny['img1.loss'])), (loss.item(), float(tiny['img1.loss']))
+    assert set(res) == {'out_l1', 'out_cos', 'hidden_rep_mse', 'embedding_mse'}
+    for k, v in res.items():
+        r = float(tiny['img1.term.' + k])
+        assert abs(v.item() - r) <= 4e-2 * abs(r) + 1e-4, (k, v.item(), r)
+    loss.backward()
+    _grad_check(s_img, tiny, 'img1.s_img.grad.', L1_TOL, 2 * L1_TOL)
+
+
+def test_feature_mse_needs_matching_widths():
+    """S-txt (768) vs T-txt (512): the reference shape-errors here as well"""
+    from distillclip_amd.model._loss import _FeatureMSEFn
+    with pytest.raises(RuntimeError, match='must match'):
+        _FeatureMSEFn.apply(torch.zeros(2, 4, 768, device='cuda'), torch.zeros(2, 4, 512, device='cuda'))
+
+
 def test_hip_vs_oracle_same_inputs_new_seed():
     """independent of the committed goldens: oracle and HIP path on a fresh seed / batch size"""
     c = TINY
