@@ -1,0 +1,123 @@
+"""The remaining BASELINE.json configurations as parity cases (real shapes, small batch), HIP path vs the oracle on the same
+seeded inputs:  image.yaml (one tower, frozen teacher embeddings)  /  text.yaml (compressed embedding)  /  336 px dual."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from distillclip_amd import synth
+
+pytestmark = pytest.mark.gpu
+os.environ['DCLIP_SYNTHETIC_TEACHER'] = '1'
+
+S_IMG = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24, mlp_ratio=4.0,
+             qkv_bias=True, repeated_times=2, use_transform=True)
+
+
+def T(d):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_image_yaml_one_tower_freeze_embed():
+    """config/final_config/image.yaml: DistillModel(model_type='image', freeze_embed=True, teacher_need_layers=[0,1,10,11])"""
+    from distillclip_amd.model import DistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer
+    seed, B = 5, 4
+    tsd = T(synth.teacher_image_state(seed))
+    tsd.update(T(synth.teacher_text_state(seed)))
+    student = RepeatVisionTransformer(**S_IMG)
+    sd = T(synth.student_image_state(seed, **S_IMG))
+    student.load_state_dict(sd)
+    m = DistillModel(student, dict(loss_name=['out_l1', 'out_cos']), './.cache', freeze_embed=True,
+                     teacher_need_layers=[0, 1, 10, 11], model_type='image', weight_decay=1e-2, lr=5e-3,
+                     teacher_state_dict=tsd).cuda()
+    image = torch.from_numpy(synth.images(seed, B))
+    loss = m.training_step(image.cuda())
+    loss.backward()
+    # oracle: same students with the teacher's patch / class / positional embeddings copied in (distil_model.py:197-213)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['patch_embed.proj.weight'] = tsd['visual.conv1.weight'].clone()
+    sd['cls_token'] = tsd['visual.class_embedding'].view(1, 1, -1).clone()
+    sd['pos_embed'] = tsd['visual.positional_embedding'].unsqueeze(0).clone()
+    for v in sd.values():
+        v.requires_grad_(True)
+    so = oracle.student_image_forward(sd, image, 24)
+    with torch.no_grad():
+        to = oracle.teacher_image_forward({k: v for k, v in tsd.items() if k.startswith('visual.')}, image)
+    ol, _ = oracle.LossOracle(['out_l1', 'out_cos'])(so, to, 'image')
+    ol.backward()
+    assert abs(loss.item() - ol.item()) <= 2e-2 * abs(ol.item()), (loss.item(), ol.item())
+    named = dict(m.student.named_parameters())
+    for frozen in ('patch_embed.proj.weight', 'cls_token', 'pos_embed'):
+        assert named[frozen].grad is None and not named[frozen].requires_grad
+    for n in ('head.weight', 'patch_embed.proj.bias', 'blocks.2.block.mlp.fc1.weight', 'blocks.0.block.attn.qkv.weight'):
+        assert rel(named[n].grad, sd[n].grad) < 1e-1, (n, rel(named[n].grad, sd[n].grad))
+    # optimizer step runs on the trainable ranges only
+    (opt,), _ = m.configure_optimizers()
+    before = named['cls_token'].detach().clone()
+    opt.step()
+    assert torch.equal(named['cls_token'], before)
+
+
+def test_text_yaml_compressed_embedding():
+    """config/final_config/text.yaml: RepeatTextTransformer(depth=4, R=2, use_transform, compression_embedding=True)"""
+    from distillclip_amd.model import DistillModel
+    from distillclip_amd.model.component import RepeatTextTransformer
+    seed, B = 6, 6
+    cfg = dict(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)
+    tsd = T(synth.teacher_image_state(seed))
+    tsd.update(T(synth.teacher_text_state(seed)))
+    student = RepeatTextTransformer(**cfg)
+    sd = T(synth.student_text_state(seed, **cfg))
+    student.load_state_dict(sd)
+    m = DistillModel(student, dict(loss_name=['out_l1', 'out_cos']), './.cache', model_type='text', teacher_state_dict=tsd).cuda()
+    text = torch.from_numpy(synth.captions(seed, B))
+    loss = m.training_step(text.cuda())
+    loss.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    so = oracle.student_text_forward(sd, text, 12)
+    with torch.no_grad():
+        to = oracle.teacher_text_forward({k: v for k, v in tsd.items() if not k.startswith('visual.')}, text)
+    ol, _ = oracle.LossOracle(['out_l1', 'out_cos'])(so, to, 'text')
+    ol.backward()
+    assert abs(loss.item() - ol.item()) <= 2e-2 * abs(ol.item()), (loss.item(), ol.item())
+    named = dict(m.student.named_parameters())
+    for n in ('head.weight', 'patch_embed.1.weight', 'patch_embed.0.weight', 'pos_embed', 'blocks.0.block.mlp.fc2.weight'):
+        assert rel(named[n].grad, sd[n].grad) < 1e-1, (n, rel(named[n].grad, sd[n].grad))
+
+
+def test_l_clip_336px_dual():
+    """BASELINE configs[4]: 336 px images -> N = (336 // 32)^2 + 1 = 101 tokens (conv floor), synthetic [101, 768] teacher pos-embed"""
+    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    seed, B = 7, 3
+    s_img_cfg = dict(S_IMG, img_size=336)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    tsd = T(synth.teacher_image_state(seed, resolution=336))
+    tsd.update(T(synth.teacher_text_state(seed)))
+    sdi, sdt = T(synth.student_image_state(seed, **s_img_cfg)), T(synth.student_text_state(seed, **s_txt_cfg))
+    si, st = RepeatVisionTransformer(**s_img_cfg), RepeatTextTransformer(**s_txt_cfg)
+    si.load_state_dict(sdi)
+    st.load_state_dict(sdt)
+    m = DualDistillModel(si, st, dict(loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1}), 15, 300, 1e-3,
+                         1e-4, './.cache', teacher_state_dict=tsd).cuda()
+    assert m.teacher.image_encoder._tower.cfg.tokens == 101 and si._tower.cfg.tokens == 101
+    image = torch.from_numpy(synth.images(seed, B, 336))
+    text = torch.from_numpy(synth.captions(seed, B))
+    loss = m.training_step([image.cuda(), text.cuda()])
+    m.backward_and_sync(loss)
+    with torch.no_grad():
+        oi, ot = oracle.student_image_forward(sdi, image, 24), oracle.student_text_forward(sdt, text, 12)
+        ti = oracle.teacher_image_forward({k: v for k, v in tsd.items() if k.startswith('visual.')}, image)
+        tt = oracle.teacher_text_forward({k: v for k, v in tsd.items() if not k.startswith('visual.')}, text)
+        ol, _ = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})(oracle.clip_forward(oi, ot), oracle.clip_forward(ti, tt), 'all')
+    assert abs(loss.item() - ol.item()) <= 2e-2 * abs(ol.item()), (loss.item(), ol.item())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.student.parameters())
