@@ -338,6 +338,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
     constexpr int BROW = HD * 2 + 32;
     constexpr int DT = HD / 16;
+    constexpr int ACH = 32 * (NMAX / 8) / 64, BCH = 32 * (HD / 8) / 64;     // 16-byte chunks per lane of a 32-row chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nprob = p.B * p.H;
@@ -350,16 +351,48 @@ __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
     const bf16_t* Bm = p.Bm + (int64_t)b * p.N * p.ldb + h * HD;
     const int ntj = (p.N + 15) >> 4;
     const int nchunk = (p.N + 31) >> 5;
+    const int acpr = p.Np >> 3;                       // A: 16-byte chunks per row
     f32x4 acc[TN_MAXJ][DT];
 #pragma unroll
     for (int j = 0; j < TN_MAXJ; ++j)
 #pragma unroll
         for (int d = 0; d < DT; ++d) acc[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // register-staged pipeline (guide T14): chunk c+1 is loaded into registers before chunk c is consumed, and written to
+    // the wave-private LDS tiles afterwards.  Rows >= N are zero (they must not contribute to the contraction).
+    u32x4 ra[ACH], rb[BCH];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < ACH; ++k) {
+            const int idx = k * 64 + lane, r = idx / acpr, c = idx - r * acpr;
+            ra[k] = u32x4{0u, 0u, 0u, 0u};
+            if (r < 32 && ch * 32 + r < p.N) ra[k] = *(const u32x4*)(A + (int64_t)(ch * 32 + r) * p.lda + c * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < BCH; ++k) {
+            const int idx = k * 64 + lane, r = idx / (HD / 8), c = idx % (HD / 8);
+            rb[k] = u32x4{0u, 0u, 0u, 0u};
+            if (ch * 32 + r < p.N) rb[k] = *(const u32x4*)(Bm + (int64_t)(ch * 32 + r) * p.ldb + c * 8);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < ACH; ++k) {
+            const int idx = k * 64 + lane, r = idx / acpr, c = idx - r * acpr;
+            if (r < 32) *(u32x4*)(at + r * TN_AROW + c * 16) = ra[k];
+        }
+#pragma unroll
+        for (int k = 0; k < BCH; ++k) {
+            const int idx = k * 64 + lane, r = idx / (HD / 8), c = idx % (HD / 8);
+            *(u32x4*)(bt + r * BROW + c * 16) = rb[k];
+        }
+    };
+    load_chunk(0);
     for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();
-        wave_stage<TN_AROW>(A, p.lda, ch * 32, p.N, 32, p.Np, at, lane);
-        wave_stage<BROW>(Bm, p.ldb, ch * 32, p.N, 32, HD, bt, lane);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        store_chunk();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (ch + 1 < nchunk) load_chunk(ch + 1);
         bf16x8 bf[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) bf[d] = tr_frag<BROW>(bt, 0, d * 16, lane);
