@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='pairs per GPU (BASELINE.json configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--teacher-text-prefix', action='store_true',
+                    help='opt-in: run the causal text teacher only on the prefix that contains every EOT (identical output, '
+                         'less work; NOT used for the headline number, which processes all 77 positions)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -118,7 +121,11 @@ def main():
     (opt,), _ = model.configure_optimizers()
     B = args.batch
     image = torch.from_numpy(synth.images(seed + rank, B)).to(device)      # per-rank shard, resident in HBM
-    text = torch.from_numpy(synth.captions(seed + rank, B)).to(device)
+    caps = synth.captions(seed + rank, B)
+    text = torch.from_numpy(caps).to(device)
+    # the tokenizer knows caption lengths on the host: the causal teacher text tower only needs the prefix holding every EOT
+    tt_tokens = int((caps != 0).sum(1).max()) if args.teacher_text_prefix else 77
+    model.set_text_length_hint(tt_tokens if args.teacher_text_prefix else None)
 
     def step():
         loss = model.training_step([image, text])
@@ -202,7 +209,8 @@ def main():
             'config': {'workload': 'l_clip.yaml dual distill: ViT-B/32 CLIP teacher -> weight-shared ViT(6x768,24h,R2) + '
                                    'text(4x768,12h,R2) students, 224px/77tok, losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW',
                        'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}',
-                       'negatives': 'local (reference training_step semantics)', 'optimizer_in_step': True},
+                       'negatives': 'local (reference training_step semantics)', 'optimizer_in_step': True,
+                       'teacher_text_tokens_processed': tt_tokens},
             'step_gflop_per_pair': STEP_GFLOP_PER_PAIR,
             'mfma_roofline_frac_whole_step': round(value / world * STEP_GFLOP_PER_PAIR * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             'final_loss': round(final_loss, 6),

@@ -104,14 +104,15 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 }
 
 template <bool OUT_F32>
-__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
-                                                           const float* __restrict__ pos, void* __restrict__ out, int rows,
-                                                           int N, int D) {
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, int id_stride,
+                                                           const float* __restrict__ table, const float* __restrict__ pos,
+                                                           void* __restrict__ out, int rows, int N, int D) {
     const int dq = D / 4;
     const int64_t total = (int64_t)rows * dq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / dq), q = (int)(i % dq);
-        float4 v = *(const float4*)(table + ids[r] * D + q * 4);
+        const int64_t id = ids[(int64_t)(r / N) * id_stride + (r % N)];      // rows of N tokens out of id_stride per caption
+        float4 v = *(const float4*)(table + id * D + q * 4);
         if (pos) {
             const float4 pv = *(const float4*)(pos + (int64_t)(r % N) * D + q * 4);
             v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
@@ -161,16 +162,17 @@ __global__ __launch_bounds__(256) void embed_hot_kernel(const int64_t* __restric
 }
 
 // idx[b] = b*N + argmax_n ids[b,n] (first maximum, like torch.argmax) ; ids == null -> b*N (class-token row)
-__global__ void pick_index_kernel(const int64_t* __restrict__ ids, int* __restrict__ idx, int B, int N) {
+__global__ void pick_index_kernel(const int64_t* __restrict__ ids, int id_stride, int* __restrict__ idx, int B, int N) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     int best = 0;
     if (ids) {
-        int64_t m = ids[(int64_t)b * N];
-        for (int n = 1; n < N; ++n) {
-            const int64_t v = ids[(int64_t)b * N + n];
+        int64_t m = ids[(int64_t)b * id_stride];
+        for (int n = 1; n < id_stride; ++n) {          // argmax over the FULL caption (reference text_encoder.py:86)
+            const int64_t v = ids[(int64_t)b * id_stride + n];
             if (v > m) { m = v; best = n; }
         }
+        best = best < N ? best : N - 1;               // contract: the EOT lies inside the processed prefix
     }
     idx[b] = b * N + best;
 }
@@ -273,12 +275,12 @@ extern "C" int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_
     return dclip_check_launch("dclip_batch_sum_acc");
 }
 
-extern "C" int dclip_embed_gather(const int64_t* ids, const float* table, const float* pos, void* out, int out_f32,
-                                  int64_t rows, int64_t N, int64_t D, void* stream) {
-    DCLIP_REQUIRE(ids && table && out && rows > 0 && N > 0 && D > 0 && D % 4 == 0, "dclip_embed_gather: bad argument");
+extern "C" int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const float* table, const float* pos, void* out,
+                                  int out_f32, int64_t rows, int64_t N, int64_t D, void* stream) {
+    DCLIP_REQUIRE(ids && table && out && rows > 0 && N > 0 && id_stride >= N && D > 0 && D % 4 == 0, "dclip_embed_gather: bad argument");
     const dim3 grid(grid_for(rows * D / 4));
-    if (out_f32) hipLaunchKernelGGL((embed_gather_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, table, pos, out, (int)rows, (int)N, (int)D);
-    else hipLaunchKernelGGL((embed_gather_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, table, pos, out, (int)rows, (int)N, (int)D);
+    if (out_f32) hipLaunchKernelGGL((embed_gather_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
+    else hipLaunchKernelGGL((embed_gather_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
     return dclip_check_launch("dclip_embed_gather");
 }
 
@@ -300,9 +302,9 @@ extern "C" int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int d
     return dclip_check_launch("dclip_embed_scatter_add");
 }
 
-extern "C" int dclip_pick_index(const int64_t* ids, int32_t* idx, int64_t B, int64_t N, void* stream) {
-    DCLIP_REQUIRE(idx && B > 0 && N > 0, "dclip_pick_index: bad argument");
-    hipLaunchKernelGGL(pick_index_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, idx, (int)B, (int)N);
+extern "C" int dclip_pick_index(const int64_t* ids, int64_t id_stride, int32_t* idx, int64_t B, int64_t N, void* stream) {
+    DCLIP_REQUIRE(idx && B > 0 && N > 0 && id_stride >= N, "dclip_pick_index: bad argument");
+    hipLaunchKernelGGL(pick_index_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, idx, (int)B, (int)N);
     return dclip_check_launch("dclip_pick_index");
 }
 

@@ -139,9 +139,11 @@ struct Work {
     size_t bytes;
 };
 
-void layout(const Plan& p, int64_t B, bool training, void* base, Work& w) {
+void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_t N = 0) {
     Bump b(base);
-    const int64_t M = B * p.N, D = p.D, F = p.F, SN = B * p.H * p.N * p.Np;
+    if (N <= 0) N = p.N;
+    const int64_t Npad = (N + 7) & ~(int64_t)7;
+    const int64_t M = B * N, D = p.D, F = p.F, SN = B * p.H * N * Npad;
     const int nex = p.L * p.R;
     const bool save = p.student && training;
     w.X.assign(nex + 1, nullptr);
@@ -169,7 +171,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w) {
         s.ctx = b.take<bf16_t>(M * D); s.h2 = b.take<bf16_t>(M * D); s.z = b.take<bf16_t>(M * F); s.u = b.take<bf16_t>(M * F);
     }
     w.patches = p.image ? b.take<bf16_t>(M * p.K) : (p.compressed ? b.take<bf16_t>(M * p.c.embed_rank) : nullptr);
-    w.tok_table = b.take<float>((int64_t)p.N * D);
+    w.tok_table = b.take<float>((int64_t)N * D);
     w.pick = b.take<int32_t>(B);
     w.meanf = b.take<float>(B); w.rstdf = b.take<float>(B);
     w.hf = b.take<bf16_t>(B * D);
@@ -178,7 +180,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w) {
         w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
         w.dbig = b.take<bf16_t>(M * F); w.dh = b.take<bf16_t>(M * D); w.dqkv = b.take<bf16_t>(M * 3 * D);
         w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
-        w.tok_sum = b.take<float>((int64_t)p.N * D);
+        w.tok_sum = b.take<float>((int64_t)N * D);
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {
         w.G = nullptr; w.Gb = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr;
@@ -279,17 +281,22 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
 
 extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
                                      const void* wcache, void* workspace, size_t ws_bytes, int training,
-                                     float* last_representation, float* const* rep_out, float* emb_out, void* st) {
+                                     float* last_representation, float* const* rep_out, float* emb_out, int64_t tokens_eff,
+                                     void* st) {
     DCLIP_REQUIRE(e && input && params && wcache && workspace && last_representation, "dclip_encoder_forward: null argument");
     DCLIP_REQUIRE(B > 0, "dclip_encoder_forward: empty batch");
     const Plan& p = e->p;
     DCLIP_REQUIRE(!training || p.student, "dclip_encoder_forward: the teacher tower is inference-only");
+    // tokens_eff: causal text teacher only.  Positions after the longest caption's EOT cannot influence any EOT row (causal
+    // attention; LN / MLP are per token), so the tower may run on the first tokens_eff positions with identical output.
+    DCLIP_REQUIRE(tokens_eff == 0 || (!p.student && !p.image && p.c.causal && tokens_eff > 0 && tokens_eff <= p.N && !rep_out && !emb_out),
+                  "dclip_encoder_forward: tokens_eff is only valid for the causal text teacher without hidden-state export");
     Work w;
-    layout(p, B, training != 0, workspace, w);
+    layout(p, B, training != 0, workspace, w, tokens_eff);
     DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
     DCLIP_REQUIRE(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)wcache % 256) == 0, "dclip_encoder_forward: buffers must be 256-byte aligned");
     const bf16_t* W = (const bf16_t*)wcache;
-    const int64_t N = p.N, D = p.D, F = p.F, E = p.E, M = B * N, H = p.H, hd = p.hd, Np = p.Np;
+    const int64_t N = tokens_eff ? tokens_eff : p.N, D = p.D, F = p.F, E = p.E, M = B * N, H = p.H, hd = p.hd, Np = (N + 7) & ~(int64_t)7;
     const float scale = 1.f / sqrtf((float)hd);
     const int nex = p.L * p.R;
 
@@ -305,11 +312,11 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
             CK(dclip_layernorm_fwd(w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, 1, nullptr, nullptr, M, D, 1e-5f, st));
         }
     } else if (p.compressed) {   // params: 0 table [V,rank], 1 linear w [D,rank], 2 linear b, 3 pos
-        CK(dclip_embed_gather((const int64_t*)input, PF(params, 0), nullptr, w.patches, 0, M, N, p.c.embed_rank, st));
+        CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), nullptr, w.patches, 0, M, N, p.c.embed_rank, st));
         CK(dclip_token_table(PF(params, 3), nullptr, PF(params, 2), w.tok_table, N, D, st));
         CK(gemm(w.patches, p.c.embed_rank, W + p.w_embed, p.c.embed_rank, w.X[0], D, M, D, p.c.embed_rank, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
     } else {                     // params: 0 table [V,D], 1 pos [N,D]
-        CK(dclip_embed_gather((const int64_t*)input, PF(params, 0), PF(params, 1), w.X[0], 1, M, N, D, st));
+        CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), PF(params, 1), w.X[0], 1, M, N, D, st));
     }
 
     // optional export of the post-positional-embedding tokens (reference ControlOutput.need_emb: _common.py:204-206 captures
@@ -363,7 +370,7 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
     }
 
     // ---- final norm + projection on the picked token only (class token / EOT = argmax of the ids) ----------------
-    CK(dclip_pick_index(p.image ? nullptr : (const int64_t*)input, w.pick, B, N, st));
+    CK(dclip_pick_index(p.image ? nullptr : (const int64_t*)input, p.N, w.pick, B, N, st));
     const int f = p.p_final;
     CK(dclip_layernorm_fwd(w.X[nex], D, w.pick, PF(params, f), PF(params, f + 1), w.hf, D, 0, w.meanf, w.rstdf, B, D, 1e-5f, st));
     CK(gemm(w.hf, D, W + p.w_head, D, last_representation, E, B, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));

@@ -120,7 +120,7 @@ class HipTower:
         self.wcache_dirty = False
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def forward(self, x, training, need_rep=False, need_emb=False, rep_layers=None):
+    def forward(self, x, training, need_rep=False, need_emb=False, rep_layers=None, tokens_eff=0):
         """-> (last_representation [B,E], input as passed to C, hidden states list, embedding or None)"""
         if not x.is_cuda:
             raise RuntimeError('distillclip_amd towers need CUDA(HIP) inputs; there is no CPU fallback')
@@ -148,7 +148,7 @@ class HipTower:
         emb = torch.empty((B, N, D), dtype=torch.float32, device=x.device) if need_emb else None
         lib().dclip_encoder_forward(self._handle, x.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
                                     self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
-                                    out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(),
+                                    out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(), int(tokens_eff),
                                     torch.cuda.current_stream().cuda_stream)
         self._saved_batch = B if training else None
         return out, x, reps, emb

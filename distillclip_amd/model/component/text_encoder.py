@@ -22,6 +22,9 @@ class TextEncoder(nn.Module):
         self.vocab_size, self.embed_dim, self.layers = vocab_size, embed_dim, transformer_layers
         self.is_student = False
         self._need_layers = need_layers
+        # optional host-side hint: number of leading positions that contain every caption's EOT (None = all context_length).
+        # The tower is causal and only the EOT row is consumed, so later positions are dead work (see include/dclip.h).
+        self.max_tokens = None
         self.token_embedding = nn.Embedding(vocab_size, transformer_width)
         nn.init.normal_(self.token_embedding.weight, std=0.02)
         self.positional_embedding = nn.Parameter(torch.randn(context_length, transformer_width) * 0.01)
@@ -45,8 +48,10 @@ class TextEncoder(nn.Module):
         if co.need_attn_score or co.need_attn_prob or co.need_value_map:
             raise NotImplementedError('teacher attention maps are not exported by the HIP tower (SURVEY.md §2.1)')
         with torch.no_grad():   # hidden states only for `need_layers` (reference _common.py:154-158)
+            hint = self.max_tokens if (self.max_tokens and not co.need_rep and not co.need_emb) else 0
             out, _, reps, emb = self._tower.forward(text, training=False, need_rep=co.need_rep, need_emb=co.need_emb,
-                                                    rep_layers=list(self.need_layers) if self.need_layers is not None else None)
+                                                    rep_layers=list(self.need_layers) if self.need_layers is not None else None,
+                                                    tokens_eff=min(int(hint), self.context_length))
         return TextTransformerOutput(last_representation=out, representations=reps, embedding=emb)
 
     def forward(self, text, control_output: ControlOutput = None):

@@ -63,6 +63,11 @@ class DualDistillModel(nn.Module):
         self._streams = None
         self.multi_stream = os.environ.get('DCLIP_MULTI_STREAM', '1') != '0'
 
+    def set_text_length_hint(self, max_tokens):
+        """Host-side knowledge of the batch (the tokenizer knows it): every caption's EOT lies in the first `max_tokens`
+        positions.  Only the frozen, causal teacher text tower uses it (the students attend over the padding)."""
+        self.teacher.text_encoder.max_tokens = max_tokens
+
     def towers(self):
         return [self.student.image_encoder._tower, self.student.text_encoder._tower]
 

@@ -116,10 +116,11 @@ int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const 
  * token_table          : out[0] = pos[0] + cls ; out[n>=1] = pos[n] + bias  (cls NULL: out[n] = pos[n] + bias)
  *                        (_common.py:199-202 ; weight_share_model.py:346-349, :489) ; token_table_bwd is its adjoint given
  *                        tok_sum[n] = sum_b G[b,n,:] from batch_sum_acc.
- * embed_gather         : out[r] = table[ids[r]] + pos[r % N] (text_encoder.py:65-66 ; weight_share_model.py:487-489).
+ * embed_gather         : out[r] = table[ids[(r / N) * id_stride + r % N]] + pos[r % N] (text_encoder.py:65-66 ;
+ *                        weight_share_model.py:487-489); id_stride = tokens per caption in `ids`, N <= id_stride = tokens used.
  * embed_scatter_add    : dtable[ids[r]] += dx[r] (f32 atomics; rows with the hot ids 0 / vocab-2 / vocab-1 = padding / SOT / EOT
  *                        of the clip.tokenize layout are reduced per block first instead of contending on three table rows).
- * pick_index           : idx[b] = b*N + argmax_n ids[b,n] (text_encoder.py:86, weight_share_model.py:506); ids NULL: b*N.
+ * pick_index           : idx[b] = b*N + argmax_n ids[b, 0..id_stride) (text_encoder.py:86, weight_share_model.py:506); ids NULL: b*N.
  * gather_rows          : out[r] = src[idx[r]] (f32).
  * adamw                : torch.optim.AdamW step on flat f32 buffers (distil_model.py:160-162, dual_distill_model.py:194-196).
  */
@@ -132,11 +133,11 @@ int dclip_token_table(const float* pos, const float* cls, const float* bias, flo
 int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D, int has_cls,
                           void* stream);
 int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_t D, void* stream);
-int dclip_embed_gather(const int64_t* ids, const float* table, const float* pos, void* out, int out_f32, int64_t rows,
-                       int64_t N, int64_t D, void* stream);
+int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const float* table, const float* pos, void* out, int out_f32,
+                       int64_t rows, int64_t N, int64_t D, void* stream);
 int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
                             int64_t vocab, void* stream);
-int dclip_pick_index(const int64_t* ids, int32_t* idx, int64_t B, int64_t N, void* stream);
+int dclip_pick_index(const int64_t* ids, int64_t id_stride, int32_t* idx, int64_t B, int64_t N, void* stream);
 int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D, void* stream);
 int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int64_t step, void* stream);
@@ -214,10 +215,13 @@ int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, v
  * training = 1 keeps every activation backward needs inside `workspace` (student only).
  * rep_out (nullable array of layers*repeats nullable f32 [B*N, D] pointers) / emb_out (nullable f32 [B*N, D]) receive the hidden
  * state after each block execution and the post-positional-embedding tokens (ControlOutput.need_rep / need_emb of the
- * reference, _loss.py:100-116); d_rep / d_emb are the matching gradients, added to the residual-stream gradient in backward. */
+ * reference, _loss.py:100-116); d_rep / d_emb are the matching gradients, added to the residual-stream gradient in backward.
+ * tokens_eff (0 = all): causal text teacher only — run the tower on the first tokens_eff positions of every caption.  The
+ * caller guarantees that every caption's EOT lies inside that prefix; positions after it cannot influence the EOT row
+ * (causal mask), so last_representation is unchanged. */
 int dclip_encoder_forward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                           const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
-                          float* const* rep_out, float* emb_out, void* stream);
+                          float* const* rep_out, float* emb_out, int64_t tokens_eff, void* stream);
 int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
                            const float* d_last_representation, const float* const* d_rep, const float* d_emb, void* stream);

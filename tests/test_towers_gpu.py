@@ -277,3 +277,29 @@ def test_real_shapes_b4_vs_reference_golden(golden_dir):
             assert rel_l2(got, g[key]) < 8e-2, (key, rel_l2(got, g[key]))
     bad = {k: v for k, v in worst.items() if v > 6e-2}
     assert not bad, bad
+
+
+def test_teacher_text_prefix_is_exact():
+    """causal teacher text tower on the prefix that holds every EOT == on all 77 positions (the EOT row cannot see later tokens)"""
+    from distillclip_amd.model.component import TextEncoder
+    seed, B = 9, 16
+    enc = TextEncoder(512, 12, 8, 77, None, 49408, 512, is_student=False)
+    sd = T(synth.teacher_text_state(seed))
+    enc.load_state_dict(sd)
+    enc = enc.cuda()
+    caps = synth.captions(seed, B)
+    text = torch.from_numpy(caps).cuda()
+    full = enc(text).last_representation.clone()
+    n_eff = int((caps != 0).sum(1).max())
+    assert n_eff < 50
+    enc.max_tokens = n_eff
+    short = enc(text).last_representation
+    assert rel_l2(short, full.cpu()) < 2e-3, rel_l2(short, full.cpu())         # same kernels, different tile boundaries
+    with torch.no_grad():
+        ref = oracle.teacher_text_forward(sd, torch.from_numpy(caps))['last_representation']
+    assert rel_l2(short, ref) < 2e-2 and cosine(short, ref) > 0.999
+    from distillclip_amd._lib import lib
+    with pytest.raises(ValueError, match='tokens_eff'):            # only the causal text teacher accepts a prefix
+        from distillclip_amd.model.component import RepeatTextTransformer
+        s = RepeatTextTransformer(depth=4, repeated_times=2, use_transform=True).cuda()
+        s._tower.forward(text, training=False, tokens_eff=40)
