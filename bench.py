@@ -96,6 +96,8 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='pairs per GPU (BASELINE.json configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--global-negatives', action='store_true',
+                    help='opt-in north-star mode: in-batch negatives over all ranks (all-gather of the embeddings over RCCL)')
     ap.add_argument('--teacher-text-prefix', action='store_true',
                     help='opt-in: run the causal text teacher only on the prefix that contains every EOT (identical output, '
                          'less work; NOT used for the headline number, which processes all 77 positions)')
@@ -109,16 +111,23 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('DCLIP_FORCE_DIST') == '1'      # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from distillclip_amd import synth
     from distillclip_amd._lib import lib
     seed = 2022                                             # main.py:24 seed_everything_default
     model = build_model(seed, device)
     (opt,), _ = model.configure_optimizers()
+    model.loss_control.global_negatives = args.global_negatives
+    if use_dist:
+        from distillclip_amd.parallel import GradSync
+        model._sync = GradSync()
+        model._sync.enabled = True          # also at world size 1 (DCLIP_FORCE_DIST): the collectives still run
     B = args.batch
     image = torch.from_numpy(synth.images(seed + rank, B)).to(device)      # per-rank shard, resident in HBM
     caps = synth.captions(seed + rank, B)
@@ -135,7 +144,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +156,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
@@ -209,7 +218,7 @@ def main():
             'config': {'workload': 'l_clip.yaml dual distill: ViT-B/32 CLIP teacher -> weight-shared ViT(6x768,24h,R2) + '
                                    'text(4x768,12h,R2) students, 224px/77tok, losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW',
                        'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}',
-                       'negatives': 'local (reference training_step semantics)', 'optimizer_in_step': True,
+                       'negatives': 'global (all-gather over RCCL)' if args.global_negatives else 'local (reference training_step semantics)', 'optimizer_in_step': True,
                        'teacher_text_tokens_processed': tt_tokens},
             'step_gflop_per_pair': STEP_GFLOP_PER_PAIR,
             'mfma_roofline_frac_whole_step': round(value / world * STEP_GFLOP_PER_PAIR * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -220,7 +229,7 @@ def main():
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -42,6 +42,7 @@ class HipTower:
         self.workspace = None
         self._ws_key = None
         self._saved_batch = None
+        self.bwd_done = None
 
     def __del__(self):
         try:
@@ -171,6 +172,11 @@ class HipTower:
                                      _ptr_array(keep) if any(g is not None for g in keep) else None,
                                      None if d_emb is None else d_emb.data_ptr(), torch.cuda.current_stream().cuda_stream)
         self._saved_batch = None
+        # gradient exchange may start as soon as THIS tower's backward is done (GradSync waits on this event, not on the
+        # whole backward pass): the image tower's all-reduce overlaps the (longer) text tower backward
+        if self.bwd_done is None:
+            self.bwd_done = torch.cuda.Event()
+        self.bwd_done.record(torch.cuda.current_stream())
 
 
 class _TowerFn(torch.autograd.Function):

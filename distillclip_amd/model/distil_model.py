@@ -69,7 +69,7 @@ class DistillModel(nn.Module):
         loss.backward()
         if self._sync is None:
             self._sync = GradSync()
-        self._sync.launch(self.student._tower.flat_grad)
+        self._sync.launch(self.student._tower.flat_grad, after=self.student._tower.bwd_done)
         self._sync.wait()
 
     def configure_optimizers(self):

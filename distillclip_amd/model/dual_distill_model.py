@@ -124,7 +124,7 @@ class DualDistillModel(nn.Module):
         if self._sync is None:
             self._sync = GradSync()
         for tw in self.towers():
-            self._sync.launch(tw.flat_grad)
+            self._sync.launch(tw.flat_grad, after=tw.bwd_done)
         self._sync.wait()
 
     def configure_optimizers(self):

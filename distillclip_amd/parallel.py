@@ -17,14 +17,18 @@ class GradSync:
         self._stream = None
         self._pending = []
 
-    def launch(self, flat_grad):
-        """average `flat_grad` across ranks, asynchronously with respect to the compute stream."""
+    def launch(self, flat_grad, after=None):
+        """average `flat_grad` across ranks, asynchronously with respect to the compute stream.  `after`: CUDA event that
+        marks the buffer complete (a tower's end-of-backward event); default = everything enqueued on the current stream."""
         if not self.enabled or flat_grad is None:
             return
         if flat_grad.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
-            self._stream.wait_stream(torch.cuda.current_stream())
+            if after is not None:
+                self._stream.wait_event(after)
+            else:
+                self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 for b in range(0, flat_grad.numel(), self.bucket):
                     chunk = flat_grad[b:b + self.bucket]
@@ -49,7 +53,7 @@ def gather_embeddings(tensors):
     gathered batch and keeps the gradient rows of its own shard, so no reduce-scatter of embedding gradients is needed; the
     gradient is scaled by `world` so that the DDP *average* of parameter gradients equals the single-process gradient of the
     loss on the concatenated batch."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return list(tensors), 0, 1
     world, rank = dist.get_world_size(), dist.get_rank()
     packed = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()          # [B, k*E]: one fused gather
