@@ -62,6 +62,21 @@ for f, d in traffic.items():
     d['hbm_bytes_per_launch'] = d.get('fetch_bytes_per_launch', 0.0) + d.get('write_bytes_per_launch', 0.0)
 json.dump(traffic, open(os.path.join(out, f'{tag}_traffic.json'), 'w'), indent=1, sort_keys=True)
 
+# MFMA utilisation per family: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)
+mfma = {}
+fs = glob.glob(os.path.join(ROOT, f'gpurun_out/prof_{tag}_mfma/*/*_counter_collection.csv'))
+if fs:
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(fs[0])):
+        per[(r['Dispatch_Id'], family(r['Kernel_Name']))][r['Counter_Name']] = float(r['Counter_Value'])
+    agg = collections.defaultdict(lambda: [0.0, 0.0])
+    for (_, f), c in per.items():
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
+            agg[f][0] += c['SQ_VALU_MFMA_BUSY_CYCLES']
+            agg[f][1] += c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0
+    mfma = {f: v[0] / v[1] for f, v in agg.items() if v[1] > 0 and v[0] > 0}
+    json.dump(mfma, open(os.path.join(out, f'{tag}_mfma_util.json'), 'w'), indent=1, sort_keys=True)
+
 with open(os.path.join(out, f'{tag}_summary.md'), 'w') as f:
     f.write(f'# rocprofv3 --kernel-trace --stats, bench.py (l_clip dual step, B=512, 1x MI355X) — {tag}\n\n')
     f.write(f'total GPU kernel time {tot / 1e6:.1f} ms over the run ({steps} steps incl. warm-up / probe)\n\n')
@@ -75,4 +90,9 @@ with open(os.path.join(out, f'{tag}_summary.md'), 'w') as f:
         f.write('\n## HBM traffic per launch (PMC passes; 2*FETCH_SIZE + WRITE_SIZE, KiB counters)\n\n| family | MB / launch |\n|---|---|\n')
         for k, d in sorted(traffic.items(), key=lambda x: -x[1]['hbm_bytes_per_launch'] * x[1].get('launches_fetch', 1))[:12]:
             f.write(f"| {k} | {d['hbm_bytes_per_launch'] / 1e6:.1f} |\n")
+if mfma:
+    with open(os.path.join(out, f'{tag}_summary.md'), 'a') as f:
+        f.write('\n## MFMA utilisation (PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))\n\n| family | MFMA pipe busy |\n|---|---|\n')
+        for k, v in sorted(mfma.items(), key=lambda x: -x[1]):
+            f.write(f'| {k} | {100 * v:.1f} % |\n')
 print('wrote profiles/', tag)
