@@ -145,3 +145,20 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     o1 = ops.gemm_nt(a, b)
     for _ in range(5):
         assert torch.equal(ops.gemm_nt(a, b), o1)
+
+
+def test_gelu_epilogue_accuracy_over_range():
+    """the fused exact-GELU / GELU' epilogues use a branch-free erf (A&S 7.1.26): check against torch over the whole range"""
+    from distillclip_amd import ops
+    n = 256
+    a = torch.eye(n, dtype=torch.bfloat16, device='cuda')
+    x = torch.linspace(-9, 9, n * n, device='cuda').reshape(n, n).to(torch.bfloat16)     # identity GEMM: out = act(x^T)
+    ref = x.float().t()
+    out = ops.gemm_nt(a, x, act='gelu', out_dtype=torch.float32)
+    assert (out - torch.nn.functional.gelu(ref)).abs().max().item() < 2e-6
+    z = x.t().contiguous()
+    zf = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zf).sum().backward()
+    ones = torch.ones(n, n, dtype=torch.bfloat16, device='cuda')
+    d = ops.gemm_nt(a, ones, act='dgelu', aux_in=z, out_dtype=torch.float32)               # 1 * gelu'(z)
+    assert (d - zf.grad).abs().max().item() < 2e-6

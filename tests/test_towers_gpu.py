@@ -264,19 +264,31 @@ def test_real_shapes_b4_vs_reference_golden(golden_dir):
         r = float(g['term.' + k])
         assert abs(v.item() - r) <= 6e-2 * abs(r) + 1e-3, (k, v.item(), r)   # 9-sample statistics at B=3 amplify bf16 noise
     loss.backward()
-    worst = {}
-    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
-        for n, p in m.named_parameters():
-            ref = float(g[f'{tag}.gnorm.{n}'])
-            got = p.grad.norm().item()
-            if ref > 0:
-                worst[f'{tag}.{n}'] = abs(got - ref) / ref
-        for key in [k for k in g if k.startswith(f'{tag}.gslice.')]:
-            n = key[len(tag) + 8:]
-            got = dict(m.named_parameters())[n].grad.reshape(-1)[:256]
-            assert rel_l2(got, g[key]) < 8e-2, (key, rel_l2(got, g[key]))
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
-    assert not bad, bad
+
+    def check(prefix, slice_tol):
+        worst = {}
+        for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+            for n, p in m.named_parameters():
+                ref = float(g[f'{prefix}{tag}.gnorm.{n}'])
+                if ref > 0:
+                    worst[f'{tag}.{n}'] = abs(p.grad.norm().item() - ref) / ref
+            for key in [k for k in g if k.startswith(f'{prefix}{tag}.gslice.')]:
+                n = key[len(prefix) + len(tag) + 8:]
+                got = dict(m.named_parameters())[n].grad.reshape(-1)[:256]
+                assert rel_l2(got, g[key]) < slice_tol, (key, rel_l2(got, g[key]))
+        bad = {k: v for k, v in worst.items() if v > 6e-2}
+        assert not bad, bad
+    # l_clip objective: norms are stable; 256-element slices of deep-layer gradients move by several % when ONE of the
+    # B*E = 2048 sign(s - t) terms of out_l1 flips under a 1e-7 perturbation of the forward -> loose bound on slices
+    check('', L1_TOL)
+    # smooth objective (out_cos only, generated by the reference as well): tight bound on the same slices
+    for p in student.parameters():
+        p.grad = None
+    lc2 = LossCalculator(['out_cos'])
+    loss2, _ = lc2(student(text, image), to, 'all')
+    assert abs(loss2.item() - float(g['cos.loss'])) <= 1e-2 * abs(float(g['cos.loss']))
+    loss2.backward()
+    check('cos.', 6e-2)
 
 
 def test_teacher_text_prefix_is_exact():

@@ -272,6 +272,20 @@ def real_shapes():
                   'blocks.1.block.mlp.fc2.weight', 'pos_embed'):
             g = dict(m.named_parameters())[n].grad
             out[f'{tag}.gslice.{n}'] = np_(g.reshape(-1)[:256])
+    # second objective: smooth (out_cos only) -> gradients are not subject to the sign / relu discontinuities of
+    # out_l1 / cos_diff, so slices can be compared tightly
+    student.zero_grad()
+    lc2 = quiet(LossCalculator, loss_name=['out_cos'])
+    so = student(text, image, lc2.get_control_output())
+    loss2, _ = lc2(so, to, 'all')
+    loss2.backward()
+    out['cos.loss'] = np_(loss2)
+    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+        for n, p in m.named_parameters():
+            out[f'cos.{tag}.gnorm.{n}'] = np_(p.grad.norm())
+        for n in ('head.weight', 'blocks.0.block.attn.qkv.weight', 'blocks.0.block.attn.conv_l.instances.1.weight',
+                  'blocks.1.block.mlp.fc2.weight', 'pos_embed'):
+            out[f'cos.{tag}.gslice.{n}'] = np_(dict(m.named_parameters())[n].grad.reshape(-1)[:256])
     np.savez_compressed(os.path.join(OUT, 'real_b4.npz'), **out)
     print('real_b4.npz', len(out), 'arrays', 'loss', float(loss))
 
