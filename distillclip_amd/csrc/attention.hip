@@ -595,11 +595,13 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
             rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tP + c * ROWB + (ks * 16 + hh * 8) * 2), ones, rs, 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = __builtin_amdgcn_rcpf(rs[r]);
+#pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pv = g < H ? am[ct][r] / rs[r] : 0.f;
+                const float pv = g < H ? am[ct][r] * rs[r] : 0.f;
                 const bf16_t phi = f2bf(pv);
                 *(bf16_t*)(tP + g * ROWB + (32 * ct + c) * 2) = phi;                       // saved P (bf16) = the hi part
                 *(bf16_t*)(tL + g * ROWB + (32 * ct + c) * 2) = f2bf(pv - bf2f(phi));    // lo part, over the dead S_lo tile

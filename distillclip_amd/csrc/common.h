@@ -62,7 +62,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x)); }   // v_rcp_f32: 1 ulp
 // exact-GELU pieces with a branch-free erf (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, i.e. at the f32 rounding level of
 // libdevice's erff but ~4x fewer instructions; the activations are stored as bf16 anyway).  phi = exp(-x^2/2) is shared
 // between erf(x / sqrt2) and the density term of the derivative.

@@ -710,6 +710,7 @@ bool use_256(const GemmNT& p) {
     static const int mode = [] { const char* e = getenv("DCLIP_GEMM256"); return e ? atoi(e) : 2; }();
     if (mode == 0 || p.M < 1024 || p.N < 256) return false;
     if (mode == 2) return true;     // default: with the towers on four streams, other kernels fill the 256^2 kernel's tail waves
+    if (mode == 3) return !(p.K <= 768 && p.N <= 768);      // experiment: tiny-K / narrow-N GEMMs on the 128^2 kernel
     // wave quantisation on 256 CUs: the 256^2 kernel runs 1 workgroup / CU, the 128^2 kernel 2 / CU.  Measured intrinsic
     // advantage of the 256^2 pipeline at equal fill: ~1.2x (tools/diag/gemm_shapes.py).
     const double t256 = (double)((p.M + 255) / 256) * ((p.N + 255) / 256);
