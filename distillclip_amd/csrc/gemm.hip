@@ -595,6 +595,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 // ds_read_b64_tr_b16 address: the 32 lanes of a half-wave (2 groups x 4 rows x 32 B) then cover all 64 banks once.
 // ------------------------------------------------------------------------------------------------------
 constexpr int TNB = TC * 256;                   // 16 KiB operand tile
+constexpr int TCLD = 128 + 4;                   // f32 row stride of the C tile staged for the atomics
+constexpr int TN_LDS = (4 * TNB > 128 * TCLD * 4) ? 4 * TNB : 128 * TCLD * 4;
 
 __device__ __forceinline__ int tn_key(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
@@ -671,20 +673,189 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    const int colb = q0 + wq * 64 + (lane & 15);
-    const int rowb = p0 + wp * 64 + (lane >> 4) * 4;
+    // epilogue: stage the 128x128 f32 tile through LDS (operand buffers are dead) so that every atomic wave-instruction
+    // adds 64 consecutive floats of one output row = 256 contiguous bytes (the full-rate shape, MI355X_MICROARCH.md
+    // "Global float atomics"), instead of four 64-byte segments straight from the accumulator layout.
+    __syncthreads();
+    float* cs = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rowb + i * 16 + r;
-            if (row >= p.P) continue;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = colb + j * 16;
-                if (col < p.Q) unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, acc[i][j][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                cs[(wp * 64 + i * 16 + (lane >> 4) * 4 + r) * TCLD + wq * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 64; ++it) {
+        const int rl = wave * 32 + (it >> 1), cl = (it & 1) * 64 + lane;
+        const int row = p0 + rl, col = q0 + cl;
+        if (row < p.P && col < p.Q) unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, cs[rl * TCLD + cl]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad on the 256x256 staggered pipeline (P % 256 == 0, Q % 256 == 0, M % 64 == 0): same half-tile ring, phase schedule,
+// counted vmcnt and wave-group stagger as gemm_nt256_kernel; the half-tiles are k-major [64 rows of M][128 columns]
+// (256-byte rows, tn_key swizzle), fragments come from ds_read_b64_tr_b16.  Every workgroup owns one output tile and one
+// slice of the token axis (long contraction = the regime this pipeline is best at); partial tiles are added with
+// row-contiguous f32 atomics staged through LDS.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, char* buf, int wave,
+                                              int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int piece = wave * 2 + s;                 // 16 pieces of 4 rows per half-tile, 2 per wave
+        const int r = piece * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ tn_key(r);
+        const bf16_t* src = G + (int64_t)(m0 + r) * ld + c0 + lc * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + piece * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int t = blockIdx.x;
+    const int split = t % p.splits; t /= p.splits;
+    const int tq = t % p.tiles_q, tp = t / p.tiles_q;
+    const int p0 = tp * 256, q0 = tq * 256;
+    const int m_begin = split * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    if (m_begin >= m_end) return;
+    const int nk = (m_end - m_begin) / TC;
+    const int nload = 4 * nk;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // half-tile l = 4*chunk + w ; w: 0 B_lo, 1 B_hi (X columns q0 + w*128), 2 A_lo, 3 A_hi (dY columns p0 + (w-2)*128)
+    auto issue = [&](int l) {
+        const int kt = l >> 2, w = l & 3;
+        char* buf = smem + ((kt & 1) * 4 + w) * HT;
+        if (w < 2) stage_half_tn(p.B, p.ldb, m_begin + kt * TC, q0 + w * 128, buf, wave, lane);
+        else stage_half_tn(p.A, p.lda, m_begin + kt * TC, p0 + (w - 2) * 128, buf, wave, lane);
+    };
+    const int npro = nload < 5 ? nload : 5;
+    for (int l = 0; l < npro; ++l) issue(l);
+    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    const int a_off = (2 + wr) * HT;
+    const int b_off = (wc >> 1) * HT;
+    const int bcol = (wc & 1) * 64;                    // this wave's 64 columns inside its B half
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * 4 * HT;
+        const char* at = base + a_off;
+        const char* bt = base + b_off;
+        const int k4 = kt * 4;
+        // phase 0 : rows 0-63 x cols 0-31
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b0[j][kb] = tr_frag_swz(bt, kb * 32, bcol + j * 16, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, i * 16, lane);
+        if (k4 + 5 < nload) issue(k4 + 5);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1 : rows 0-63 x cols 32-63
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b1[j][kb] = tr_frag_swz(bt, kb * 32, bcol + (2 + j) * 16, lane);
+        if (k4 + 6 < nload) issue(k4 + 6);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 2 : rows 64-127 x cols 32-63
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, (4 + i) * 16, lane);
+        if (k4 + 7 < nload) issue(k4 + 7);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[4 + i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 3 : rows 64-127 x cols 0-31
+        if (k4 + 8 < nload) { issue(k4 + 8); WAIT_VMCNT(2); }
+        else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // epilogue: 4 slabs of 64 rows through LDS, then row-contiguous f32 atomics (256 lanes x 4 B = 1 KiB per row)
+    float* cs = (float*)smem;
+    constexpr int CL = 256 + 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cs[(wr * 32 + i * 16 + (lane >> 4) * 4 + r) * CL + wc * 64 + j * 16 + (lane & 15)] = acc[q * 2 + i][j][r];
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int sl = (tid >> 8) + it * 2;                          // slab row 0..63, 256 threads per row
+            const int row = p0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+            const int col = q0 + (tid & 255);
+            unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, cs[sl * CL + (tid & 255)]);
         }
+    }
 }
 
 // column sums: grid (ceil(N/256) , row_splits); each thread owns one column, strides rows
@@ -789,8 +960,24 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     const int grid = p.tiles_p * p.tiles_q * p.splits;
     static const int tn_mode = [] { const char* e = getenv("DCLIP_TN_GLDS"); return e ? atoi(e) : 1; }();
     const bool fast = tn_mode != 0 && M % TC == 0 && P >= 8 && Q >= 8;
+    // 256^2 pipeline for the large outputs: one workgroup per CU, every workgroup a long slice of the token axis
+    static const int tn256_mode = [] { const char* e = getenv("DCLIP_TN256"); return e ? atoi(e) : 1; }();
+    if (tn256_mode != 0 && fast && P % 256 == 0 && Q % 256 == 0 && (P / 256) * (Q / 256) >= 16 && M >= 4096) {
+        GemmTN q = p;
+        q.tiles_p = (int)(P / 256); q.tiles_q = (int)(Q / 256);
+        const int tiles = q.tiles_p * q.tiles_q;
+        int s = (256 + tiles / 2) / tiles;                      // ~ one workgroup per CU
+        if (s < 1) s = 1;
+        int ch = (int)((M + s - 1) / s);
+        ch = ((ch + TC - 1) / TC) * TC;
+        q.chunk = ch;
+        q.splits = (int)((M + ch - 1) / ch);
+        TraceScope tr2(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 8 * HT, (hipStream_t)stream, q);
+        return dclip_check_launch("dclip_gemm_tn_acc");
+    }
     TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
-    if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), 4 * TNB, (hipStream_t)stream, p);
+    if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), TN_LDS, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
     return dclip_check_launch("dclip_gemm_tn_acc");
 }

@@ -107,6 +107,20 @@ def test_gemm_tn_acc(M, P, Q, splits):
     _close(dw, ref, 1e-5 * M ** 0.5 + 1e-5)
 
 
+@pytest.mark.parametrize('M,P,Q', [(4096, 1024, 1024), (8192, 3072, 768), (6400, 768, 3072), (4160, 2304, 768)])
+def test_gemm_tn_256_pipeline(M, P, Q):
+    """wgrad shapes routed to the 256x256 staggered pipeline (P, Q % 256 == 0, >= 16 tiles, M % 64 == 0)"""
+    from distillclip_amd import ops
+    a, b = _rand((M, P), 31), _rand((M, Q), 32)
+    dw = torch.full((P, Q), 0.5, device='cuda')
+    ops.gemm_tn_acc(a, b, dw, 4)
+    ref = 0.5 + a.float().t() @ b.float()
+    _close(dw, ref, 1e-5 * M ** 0.5 + 1e-5)
+    # a second, independent accumulation must add exactly one more product (no lost / duplicated atomics)
+    ops.gemm_tn_acc(a, b, dw, 4)
+    _close(dw, 2 * ref - 0.5, 1e-5 * M ** 0.5 + 1e-5)
+
+
 def test_gemm_tn_asymmetric():
     from distillclip_amd import ops
     M = 64
