@@ -163,20 +163,23 @@ def main():
     final_loss = loss.item()
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # dominant kernel = gemm_nt_kernel (forward linears + dgrad): HIP events around every launch of 2 further steps,
-        # recorded on the launch stream by the library's trace hooks (include/dclip.h: dclip_trace_*)
+    if not args.no_roofline:
+        # dominant kernel = gemm_nt (forward linears + dgrad): HIP events around every launch of 2 further steps, recorded on the
+        # launch stream by the library's trace hooks (include/dclip.h: dclip_trace_*).  EVERY rank runs these steps (they contain
+        # the gradient collectives); only rank 0 traces.
         import ctypes
         cap = 20000
         nprobe = 2
         multi, model.multi_stream = model.multi_stream, False      # one stream: event intervals then bracket one kernel each
         step()
         torch.cuda.synchronize()
-        lib().dclip_trace_begin(cap)
+        if rank == 0:
+            lib().dclip_trace_begin(cap)
         for _ in range(nprobe):
             step()
         torch.cuda.synchronize()
         model.multi_stream = multi
+    if rank == 0 and not args.no_roofline:
         kind = (ctypes.c_int32 * cap)()
         ms = (ctypes.c_float * cap)()
         fl = (ctypes.c_double * cap)()
@@ -196,7 +199,8 @@ def main():
         tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
         if tj:
             traffic = json.load(open(tj[-1])).get('gemm_nt', {}).get('hbm_bytes_per_launch')
-        roofline = {'kernel': 'gemm_nt (gemm_nt_kernel 128x128 + gemm_nt256_kernel 256x256)', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
+        roofline = {'kernel': 'gemm_nt (gemm_nt_kernel 128x128 + gemm_nt256_kernel 256x256)', 'bound': 'mfma',
+                    'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                     'algorithmic_bytes_per_launch': g[3] / g[0],
                     'launches_per_step': g[0] // nprobe, 'avg_launch_us': round(g[1] / g[0] * 1e3, 2),

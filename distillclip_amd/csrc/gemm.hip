@@ -966,7 +966,8 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
         GemmTN q = p;
         q.tiles_p = (int)(P / 256); q.tiles_q = (int)(Q / 256);
         const int tiles = q.tiles_p * q.tiles_q;
-        int s = (256 + tiles / 2) / tiles;                      // ~ one workgroup per CU
+        static const int tn256_blocks = [] { const char* e = getenv("DCLIP_TN256_BLOCKS"); return e ? atoi(e) : 256; }();
+        int s = (tn256_blocks + tiles / 2) / tiles;             // ~ one workgroup per CU
         if (s < 1) s = 1;
         int ch = (int)((M + s - 1) / s);
         ch = ((ch + TC - 1) / TC) * TC;
