@@ -661,10 +661,11 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
     constexpr int COLS = 64 * NS, ROWB = COLS * 2 + 16, NCT = COLS / 32, TILE = 32 * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* tR = smem + wave * 3 * TILE;
-    char* tP = tR + TILE;
-    char* tS = tP + TILE;
-    for (int idx = lane; idx < 3 * TILE / 16; idx += 64) ((u32x4*)tR)[idx] = u32x4{0u, 0u, 0u, 0u};
+    char* tR = smem + wave * 4 * TILE;      // dR
+    char* tP = tR + TILE;                   // P
+    char* tS = tP + TILE;                   // S (bf16)
+    char* tD = tS + TILE;                   // dA
+    for (int idx = lane; idx < 4 * TILE / 16; idx += 64) ((u32x4*)tR)[idx] = u32x4{0u, 0u, 0u, 0u};
     const int hh = lane >> 5, c = lane & 31;
     bf16x8 aWw[2], aWl[2], aI[2];
 #pragma unroll
@@ -687,6 +688,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
     const int64_t hs = (int64_t)p.N * p.Np;
     const int rows = p.B * p.N;
     const int nchunk = p.Np >> 3, total = H * nchunk;
+    const int nct = (p.N + 31) >> 5;                 // key tiles that hold real keys (the rest is all padding)
+    const int nks = nct * 2;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const int b = row / p.N, i = row % p.N;
         const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
@@ -702,72 +705,70 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // Cw = dR P^T
-        f32x16 cw = {0};
-#pragma unroll
-        for (int ks = 0; ks < COLS / 16; ++ks) {
-            const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
-            cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tR + off), *(const bf16x8*)(tP + off), cw, 0, 0, 0);
-        }
+        // Cw = dR P^T  (this row's dW_w contribution) and the softmax row sums rs[h] = sum_g Ww[g,h] Cw[g,h]
         float part = 0.f;
+        {
+            f32x16 cw = {0};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part = fmaf(wwc[r], cw[r], part);
-        part += __shfl_xor(part, 32);                      // lanes h and h + 32 now hold rs[h]
-        // dP = Ww^T dR and P in accumulator layout (row h in registers, key j on the lane)
-        f32x16 dp[NCT], pa[NCT];
+            for (int ks = 0; ks < COLS / 16; ++ks)
+                if (ks < nks) {
+                    const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
+                    cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tR + off), *(const bf16x8*)(tP + off), cw, 0, 0, 0);
+                }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            dp[ct] = f32x16{0}; pa[ct] = f32x16{0};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                dp[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWw[s], tr_frag32<ROWB>(tR, 16 * s, 32 * ct, lane), dp[ct], 0, 0, 0);
-                pa[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[s], tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), pa[ct], 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) part = fmaf(wwc[r], cw[r], part);
+            accw += cw;
         }
-        accw += cw;
-        // dA = P o (dP - rs[h]) ; row of register r is h = (r&3) + 8*(r>>2) + 4*hh
+        part += __shfl_xor(part, 32);                      // lanes h and h + 32 now hold rs[h]
+        float rsr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int h0 = (r & 3) + 8 * (r >> 2);
-            const float rs = hh ? lane_bcast(part, h0 + 4) : lane_bcast(part, h0);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) dp[ct][r] = pa[ct][r] * (dp[ct][r] - rs);       // dp now holds dA
+            rsr[r] = hh ? lane_bcast(part, h0 + 4) : lane_bcast(part, h0);
         }
-        // dA -> LDS rows (over the dR tile, which is dead) for the dW_l product
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) *(bf16_t*)(tR + h * ROWB + (32 * ct + c) * 2) = f2bf(dp[ct][r]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ks = 0; ks < COLS / 16; ++ks) {
-            const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
-            accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tR + off), *(const bf16x8*)(tS + off), accl, 0, 0, 0);
-        }
-        // dS = Wl^T dA, B operand straight from the dA accumulator registers
+        // one key tile at a time: dP = Ww^T dR, P in accumulator layout, dA = P o (dP - rs), dS = Wl^T dA
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            f32x16 ds = {0};
+            if (ct < nct) {
+                f32x16 dp = {0}, pa = {0};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 bf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bf[e] = f2bf(dp[ct][8 * s + e]);
-                ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf, ds, 0, 0, 0);
-            }
-            const int j = 32 * ct + c;
-            if (j < p.Np) {
+                for (int s = 0; s < 2; ++s) {
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWw[s], tr_frag32<ROWB>(tR, 16 * s, 32 * ct, lane), dp, 0, 0, 0);
+                    pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[s], tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), pa, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (h < H) p.dS[base + h * hs + j] = f2bf(ds[r]);
+                    dp[r] = pa[r] * (dp[r] - rsr[r]);                                   // dA
+                    *(bf16_t*)(tD + h * ROWB + (32 * ct + c) * 2) = f2bf(dp[r]);
+                }
+                f32x16 ds = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 bf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[e] = f2bf(dp[8 * s + e]);
+                    ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf, ds, 0, 0, 0);
+                }
+                const int j = 32 * ct + c;
+                if (j < p.Np) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (h < H) p.dS[base + h * hs + j] = f2bf(ds[r]);
+                    }
                 }
             }
         }
+        // dW_l += dA S^T
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < COLS / 16; ++ks)
+            if (ks < nks) {
+                const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tD + off), *(const bf16x8*)(tS + off), accl, 0, 0, 0);
+            }
     }
     // accumulators: element (g = (r&3) + 8*(r>>2) + 4*hh, h = c)
 #pragma unroll
@@ -919,8 +920,9 @@ extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const float
     if (Wl) {
         // ~280 registers -> one resident workgroup per CU: launch one persistent workgroup per CU so the per-workgroup
         // setup (LDS zero-fill, constant Ww / Wl fragments) is amortised over all its rows
-        if (blocks > 256) blocks = 256;
-        const size_t lds = (size_t)4 * 3 * 32 * (64 * ns * 2 + 16);
+        const size_t lds = (size_t)4 * 4 * 32 * (64 * ns * 2 + 16);
+        const int per_cu = lds <= 80 * 1024 ? 2 : 1;        // persistent workgroups: setup amortised over all rows
+        if (blocks > 256 * per_cu) blocks = 256 * per_cu;
         SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_mix_kernel<HH, NSS>), dim3(blocks), dim3(256), lds, st, p));
     } else {
         SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_bwd_plain_kernel<HH, NSS>), dim3(blocks), dim3(256), 0, st, p));
