@@ -88,6 +88,16 @@ __device__ __forceinline__ float dgelu_erf_f(float x) {
     return fmaf(x * phi, 0.3989422804014327f, cdf);
 }
 
+// gelu(x) and gelu'(x) together: the derivative costs two more instructions once the pieces of gelu are there, so the forward
+// epilogue can hand the backward its factor instead of the pre-activation (DCLIP_ACT_GELU_SAVE / DCLIP_ACT_MULAUX).
+__device__ __forceinline__ void gelu_erf_both_f(float x, float& g, float& dg) {
+    const float phi = __expf(-0.5f * x * x);
+    const float tail = erf_tail(fabsf(x) * 0.70710678118654752f, phi);
+    const float cdf = x >= 0.f ? 1.f - 0.5f * tail : 0.5f * tail;
+    g = x * cdf;
+    dg = fmaf(x * phi, 0.3989422804014327f, cdf);
+}
+
 // XCD-aware, bijective remap of a linear workgroup id: blocks that share an XCD (same id % 8 under the
 // observed round-robin placement) get a contiguous chunk of the tile space, so neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

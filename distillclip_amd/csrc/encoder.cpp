@@ -359,7 +359,7 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
         CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
-        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? DCLIP_ACT_GELU : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
+        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
         CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
         // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
         if (rep_out && rep_out[ei] &&
@@ -420,7 +420,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], w.Gb, M * D, GR(sb.f2b), D, st));
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         if (GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.Gb, D, s.u, F, GR(sb.f2w), F, M, D, F, wsplits(M, D, F), st));
-        CK(dclip_gemm_nt(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_DGELU, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
+        CK(dclip_gemm_nt(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_MULAUX, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
                          GR(sb.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
         if (GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s.h2, D, GR(sb.f1w), D, M, F, D, wsplits(M, F, D), st));
         CK(gemm(w.dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));

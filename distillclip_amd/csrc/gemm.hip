@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
         }
         const int64_t o = (int64_t)row * p.ldc + col;
-        if (p.aux_out) {
+        if (ACT != 5 && p.aux_out) {
             bf16x8 z;
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
@@ -173,6 +173,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
+        }
+        if (ACT == 4) {
+            const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= bf2f(z[e]);
+        }
+        if (ACT == 5) {
+            bf16x8 dz;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float g, dg;
+                gelu_erf_both_f(v[e], g, dg);
+                v[e] = g; dz[e] = f2bf(dg);
+            }
+            if (p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
         }
         if (p.residual) {
             const float* rp = p.residual + (int64_t)row * p.ldr + col;
@@ -253,7 +268,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
     }
     const int64_t o = (int64_t)row * p.ldc + col;
-    if (p.aux_out) {
+    if (ACT != 5 && p.aux_out) {
         bf16x8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
@@ -271,6 +286,21 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
         const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
+    }
+    if (ACT == 4) {
+        const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= bf2f(z[e]);
+    }
+    if (ACT == 5) {
+        bf16x8 dz;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g, dg;
+            gelu_erf_both_f(v[e], g, dg);
+            v[e] = g; dz[e] = f2bf(dg);
+        }
+        if (p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
     }
     if (p.residual) {
         const float* rp = p.residual + (int64_t)row * p.ldr + col;
@@ -920,8 +950,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
                   "dclip_gemm_nt: operand rows must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
     DCLIP_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0, "dclip_gemm_nt: N and ldc must be multiples of 8 and C 16-byte aligned (N=%ld ldc=%ld)", (long)N, (long)ldc);
     DCLIP_REQUIRE(!residual || (ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "dclip_gemm_nt: residual rows must be 16-byte aligned");
-    DCLIP_REQUIRE(act >= 0 && act <= 3, "dclip_gemm_nt: bad activation code %d", act);
-    DCLIP_REQUIRE(act != DCLIP_ACT_DGELU || aux_in, "dclip_gemm_nt: DGELU needs aux_in");
+    DCLIP_REQUIRE(act >= 0 && act <= 5, "dclip_gemm_nt: bad activation code %d", act);
+    DCLIP_REQUIRE((act != DCLIP_ACT_DGELU && act != DCLIP_ACT_MULAUX) || aux_in, "dclip_gemm_nt: DGELU / MULAUX need aux_in");
     DCLIP_REQUIRE(row_group == 0 || rowadd, "dclip_gemm_nt: row_group needs rowadd");
     DCLIP_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "dclip_gemm_nt: dimension overflow");
     GemmNT p;
@@ -937,7 +967,9 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
         case 0: return launch_nt<0>(p, out_f32 != 0, st);
         case 1: return launch_nt<1>(p, out_f32 != 0, st);
         case 2: return launch_nt<2>(p, out_f32 != 0, st);
-        default: return launch_nt<3>(p, out_f32 != 0, st);
+        case 3: return launch_nt<3>(p, out_f32 != 0, st);
+        case 4: return launch_nt<4>(p, out_f32 != 0, st);
+        default: return launch_nt<5>(p, out_f32 != 0, st);
     }
 }
 

@@ -4,7 +4,7 @@ import torch
 
 from ._lib import lib
 
-ACT = {'none': 0, None: 0, 'quickgelu': 1, 'gelu': 2, 'dgelu': 3}
+ACT = {'none': 0, None: 0, 'quickgelu': 1, 'gelu': 2, 'dgelu': 3, 'mulaux': 4, 'gelu_save': 5}
 
 
 def _p(t):

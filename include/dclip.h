@@ -31,14 +31,18 @@ const char* dclip_last_error_string(void);  /* thread-local */
 #define DCLIP_ACT_NONE 0
 #define DCLIP_ACT_QUICKGELU 1 /* reference model/component/_common.py:23-25 */
 #define DCLIP_ACT_GELU 2      /* exact erf GELU: timm Mlp act, reference weight_share_model.py:177 */
-#define DCLIP_ACT_DGELU 3     /* multiply by gelu'(aux_in): backward of DCLIP_ACT_GELU */
+#define DCLIP_ACT_DGELU 3     /* multiply by gelu'(aux_in): backward of DCLIP_ACT_GELU from the saved pre-activation */
+#define DCLIP_ACT_MULAUX 4    /* multiply by aux_in: backward of DCLIP_ACT_GELU_SAVE */
+#define DCLIP_ACT_GELU_SAVE 5 /* DCLIP_ACT_GELU whose aux_out receives gelu'(pre-activation) instead of the pre-activation */
 
 /*
  * C[M,N] = epilogue(alpha * A[M,K] · B[N,K]^T)        (nn.Linear / F.linear / x @ proj / conv-as-GEMM)
  *   reference: _common.py:59,90,104-108,213 ; text_encoder.py:72 ; weight_share_model.py:90,132,177,364
  *   A, B bf16 (lda, ldb in elements; K % 64 == 0; 16-byte aligned rows).
  *   epilogue, in order: + bias[N] (f32, may be NULL) ; if aux_out: store pre-activation as bf16 [M,N] (ld = ldc) ;
- *   activation `act` (DCLIP_ACT_DGELU multiplies by gelu'(aux_in[M,N] bf16, ld = ldc)) ;
+ *   activation `act` (DCLIP_ACT_DGELU multiplies by gelu'(aux_in[M,N] bf16, ld = ldc); DCLIP_ACT_GELU_SAVE stores
+ *   gelu'(pre-activation) in aux_out instead, which DCLIP_ACT_MULAUX multiplies by: the training towers use that pair, the
+ *   derivative being two extra instructions in the forward epilogue and a single multiply in the backward one) ;
  *   + residual[M,N] (f32, ld = ldr, may be NULL, may alias C when out_f32) ; store C as f32 (out_f32=1) or bf16.
  *   row_group > 0 adds `rowadd` (f32 [row_group, N]) row (r % row_group) to GEMM row r: the positional-embedding
  *   add of the token embedders (reference _common.py:196-202, text_encoder.py:65-66, weight_share_model.py:344-349,

@@ -176,3 +176,10 @@ def test_gelu_epilogue_accuracy_over_range():
     ones = torch.ones(n, n, dtype=torch.bfloat16, device='cuda')
     d = ops.gemm_nt(a, ones, act='dgelu', aux_in=z, out_dtype=torch.float32)               # 1 * gelu'(z)
     assert (d - zf.grad).abs().max().item() < 2e-6
+    # the pair the training towers use: forward stores gelu'(z) (bf16), backward multiplies by it
+    saved = torch.empty(n, n, dtype=torch.bfloat16, device='cuda')
+    out2 = ops.gemm_nt(a, x, act='gelu_save', aux_out=saved, out_dtype=torch.float32)
+    assert torch.equal(out2, out)
+    assert (saved.float() - zf.grad).abs().max().item() < 5e-3                              # one bf16 rounding of a value in [-0.13, 1.13]
+    d2 = ops.gemm_nt(a, ones, act='mulaux', aux_in=saved, out_dtype=torch.float32)
+    assert torch.equal(d2, saved.float())
