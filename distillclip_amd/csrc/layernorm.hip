@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const int stride = gridDim.x * 4;
     for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
         const int rowv[2] = {row0, row0 + stride};
-        float4 xh[2][NV], g[2][NV];
+        float4 xh[2][NV], g[2][NV], ain[2][NV];
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2];
         int64_t srcv[2];
         bool ok[2];
@@ -94,9 +94,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
-                xh[u][i] = g[u][i] = float4{0.f, 0.f, 0.f, 0.f};
+                xh[u][i] = g[u][i] = ain[u][i] = float4{0.f, 0.f, 0.f, 0.f};
                 if (c < D && ok[u]) {
                     const float4 xv = *(const float4*)(x + srcv[u] * ldx + c);
+                    ain[u][i] = *(const float4*)(dx_acc + srcv[u] * lddx + c);      // issued with the other loads, consumed after the reductions
                     float4 d;
                     if (DY_F32) d = *(const float4*)((const float*)dy + (int64_t)row * lddy + c);
                     else {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 const int c = (i * 64 + lane) * 4;
                 if (c < D) {
                     float* o = dx_acc + srcv[u] * lddx + c;
-                    float4 a = *(const float4*)o;
+                    float4 a = ain[u][i];
                     a.x += rs * (g[u][i].x - c1 - xh[u][i].x * c2);
                     a.y += rs * (g[u][i].y - c1 - xh[u][i].y * c2);
                     a.z += rs * (g[u][i].z - c1 - xh[u][i].z * c2);
