@@ -2,7 +2,8 @@
 
 The reference class is a pytorch_lightning.LightningModule; Lightning is not installed here, so the same constructor,
 `forward`, `training_step`, `configure_optimizers`, `freeze_image_embedding` are provided on a plain nn.Module (the
-methods Lightning would call).  Logging / wandb / torchmetrics validation are out of scope.
+methods Lightning would call).  `validation_step` / `validation_epoch_end` return the scalars the reference logs, computed
+by the HIP retrieval kernel (distillclip_amd/metrics.py) instead of torchmetrics; wandb / heat-map logging is not mirrored.
 """
 from typing import Dict, List
 
@@ -14,6 +15,7 @@ from .utils import teacher_load
 from .component.weight_share_model import RepeatVisionTransformer
 from ..optim import FusedAdamW, EpochCosineSchedule
 from ..parallel import GradSync
+from ..metrics import retrieval_metrics, gather_rows
 
 
 class _HParams(dict):
@@ -71,6 +73,44 @@ class DistillModel(nn.Module):
             self._sync = GradSync()
         self._sync.launch(self.student._tower.flat_grad, after=self.student._tower.bwd_done)
         self._sync.wait()
+
+    def _acc(self, log, rows, cols, section, prefix, acc=True, score=False):
+        # reference norm_and_logits :224-231 builds stu_logits = stu_encode @ encode.T : rows = this tower, cols = the other
+        m = retrieval_metrics(rows, cols, self.k_list)
+        if acc:
+            for k in self.k_list:                                          # reference log_acc :187-191
+                log[f'{section}/{prefix}_acc_top{k}'] = m[f'acc_top{k}']
+        if score:                                                          # reference log_diag_score :171-179
+            log[f'{section}/{prefix}_softmax_mean_score'] = m['softmax_mean_score']
+            log[f'{section}/{prefix}_mean_score'] = m['mean_score']
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """reference :104-126.  batch = (imgs, texts, _) where the modality that is not distilled arrives as a
+        pre-computed [B, E] teacher representation (`contrary_rep`)."""
+        imgs, texts = batch[0], batch[1]
+        inputs, contrary_rep = (texts, imgs) if self.hparams.model_type == 'text' else (imgs, texts)
+        student_outs, teacher_outs = self.forward(inputs)
+        loss, cal_res = self.loss_control(student_outs, teacher_outs, self.hparams.model_type)
+        log = {'val_loss/loss': loss.detach()}
+        log.update({f'val_loss/{k}': v for k, v in cal_res.items()})
+        s, t = student_outs.last_representation, teacher_outs.last_representation
+        self._acc(log, s, contrary_rep, 'val_step', 'stu', score=True)
+        self._acc(log, t, contrary_rep, 'val_step', 'tea')
+        return {'student': gather_rows(s), 'teacher': gather_rows(t), 'contrary_rep': gather_rows(contrary_rep)}, log
+
+    @torch.no_grad()
+    def validation_epoch_end(self, outputs):
+        """reference :131-152"""
+        cat = {k: torch.cat([o[k].reshape(-1, o[k].shape[-1]) for o in outputs], dim=0).float()
+               for k in ('student', 'teacher', 'contrary_rep')}
+        log = {}
+        self._acc(log, cat['student'], cat['contrary_rep'], 'val_stu_acc', 'stu')
+        self._acc(log, cat['student'], cat['contrary_rep'], 'val_stu_score', 'stu', acc=False, score=True)
+        if self.current_epoch == 0:
+            self._acc(log, cat['teacher'], cat['contrary_rep'], 'val_tea_score', 'tea', acc=False, score=True)
+            self._acc(log, cat['teacher'], cat['contrary_rep'], 'val_tea_acc', 'tea')
+        return log
 
     def configure_optimizers(self):
         # reference :160-169: AdamW over every requires_grad parameter (one group) + cosine schedule stepped per epoch

@@ -1,8 +1,9 @@
 """DualDistillModel (reference model/dual_distill_model.py:41-268): two-tower (image + text) distillation.
 
 Same constructor / forward / training_step / configure_optimizers / load_weight / freeze_with_prefix as the reference's
-LightningModule, on a plain nn.Module (Lightning, wandb and torchmetrics are absent here; validation metrics are the
-"next" row N3 of SURVEY.md §8f).
+LightningModule, on a plain nn.Module (Lightning, wandb and torchmetrics are absent here).  `validation_step` /
+`validation_epoch_end` return the dictionary of scalars the reference hands to `self.log`, computed by the HIP retrieval
+kernel (distillclip_amd/metrics.py) instead of torchmetrics.
 """
 import os
 from typing import Dict, List, Optional, Tuple
@@ -18,6 +19,7 @@ from .component.weight_share_model import RepeatVisionTransformer
 from .distil_model import _HParams
 from ..optim import FusedAdamW, EpochCosineSchedule
 from ..parallel import GradSync
+from ..metrics import retrieval_metrics, gather_rows
 
 
 def load_weight(image_student, text_student, load_path):
@@ -126,6 +128,45 @@ class DualDistillModel(nn.Module):
         for tw in self.towers():
             self._sync.launch(tw.flat_grad, after=tw.bwd_done)
         self._sync.wait()
+
+    def _acc(self, log, img, txt, section, prefix, acc=True, score=False):
+        m = retrieval_metrics(img, txt, self.k_list)
+        if acc:
+            for k in self.k_list:                                          # reference log_acc :220-224
+                log[f'{section}/{prefix}_acc_top{k}'] = m[f'acc_top{k}']
+        if score:                                                          # reference log_diag_score :204-212
+            log[f'{section}/{prefix}_softmax_mean_score'] = m['softmax_mean_score']
+            log[f'{section}/{prefix}_mean_score'] = m['mean_score']
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """reference :129-147.  -> (gathered representations for validation_epoch_end, {log key: 0-dim tensor})"""
+        student_outs, teacher_outs = self.forward(batch)
+        loss, cal_res = self.loss_control(student_outs, teacher_outs, 'all')
+        si, st = student_outs.visual_output.last_representation, student_outs.text_output.last_representation
+        ti, tt = teacher_outs.visual_output.last_representation, teacher_outs.text_output.last_representation
+        log = {'val_loss/loss': loss.detach()}
+        log.update({f'val_loss/{k}': v for k, v in cal_res.items()})
+        self._acc(log, si, st, 'val_step', 'stu', score=True)
+        self._acc(log, ti, tt, 'val_step', 'tea')
+        out = {'stu_image_outs': gather_rows(si), 'stu_text_outs': gather_rows(st),
+               'tea_image_outs': gather_rows(ti), 'tea_text_outs': gather_rows(tt)}
+        return out, log
+
+    @torch.no_grad()
+    def validation_epoch_end(self, outputs):
+        """reference :152-187: metrics over the whole validation set (5000 COCO pairs for the shipped configs)"""
+        cat = {k: torch.cat([o[k].reshape(-1, o[k].shape[-1]) for o in outputs], dim=0).float()
+               for k in ('stu_image_outs', 'stu_text_outs', 'tea_image_outs', 'tea_text_outs')}
+        log = {}
+        self._acc(log, cat['stu_image_outs'], cat['stu_text_outs'], 'val_stu_acc', 'stu')
+        self._acc(log, cat['stu_image_outs'], cat['tea_text_outs'], 'val_stu_image_tea_text', 'stu_image_tea_text')
+        self._acc(log, cat['tea_image_outs'], cat['stu_text_outs'], 'val_stu_text_tea_image', 'stu_text_tea_image')
+        self._acc(log, cat['stu_image_outs'], cat['stu_text_outs'], 'val_stu_score', 'stu', acc=False, score=True)
+        if self.current_epoch == 0:
+            self._acc(log, cat['tea_image_outs'], cat['tea_text_outs'], 'val_tea_score', 'tea', acc=False, score=True)
+            self._acc(log, cat['tea_image_outs'], cat['tea_text_outs'], 'val_tea_acc', 'tea')
+        return log
 
     def configure_optimizers(self):
         # reference :194-202

@@ -162,6 +162,19 @@ size_t dclip_distill_loss_workspace(int64_t B, int64_t E);
 int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B, int64_t E,
                        const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt, void* workspace,
                        size_t ws_bytes, void* stream);
+/*
+ * Validation retrieval metrics of one image -> caption logits matrix, without materialising it.
+ *   reference: dual_distill_model.py:271-275 (norm_and_logits), :204-212 (log_diag_score), :220-224 (log_acc with
+ *   torchmetrics accuracy(top_k = k) against labels arange(n)), k_list :87 ; distil_model.py:171-191, :224-231.
+ * img, txt: f32 [n, E] device, un-normalised (rows are divided by their L2 norm, no epsilon, as the reference does);
+ * ks: HOST array of nk <= 8 cut-offs.  out (device, nk + 2 f32): acc@ks[0..nk) (fraction of rows whose matching caption is
+ * among the ks[i] highest logits of the row; strict comparison, a tie with the diagonal counts for the diagonal),
+ * out[nk] = mean_i softmax(logits_i)[i], out[nk + 1] = mean_i logits_ii.  rank_out (device int32 [n], nullable) receives
+ * the number of captions that beat the matching one.  Other pairings (student image x teacher text, ...) are further calls.
+ */
+size_t dclip_retrieval_metrics_workspace(int64_t n, int64_t E);
+int dclip_retrieval_metrics(const float* img, const float* txt, int64_t n, int64_t E, const int32_t* ks, int nk,
+                            float* out, int32_t* rank_out, void* workspace, size_t ws_bytes, void* stream);
 /* feature MSE (hidden_rep_mse / embedding_mse: hidden_mse.py:9-17, embed_mse.py:9-10):
  *   loss_acc[0] += coef * mean((s - t)^2) ; ds_acc (nullable) += coef * 2 (s - t) / n */
 int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, float* loss_acc, float* ds_acc, void* stream);

@@ -14,6 +14,8 @@ weights/inputs (distillclip_amd/synth.py); tests/test_oracle_golden.py checks th
 restatement against them.  The timm boundary (Mlp / PatchEmbed / DropPath / trunc_normal_,
 version unpinned by the reference) is pinned against tools/golden/ref_shims, our
 restatement of timm's published semantics (see that README).
+Exception: oracle/metrics.py (validation retrieval metrics) is pinned by known-answer cases only —
+the reference computes top-k accuracy with torchmetrics, which this image lacks, so no reference-run golden exists.
 """
 from .encoders import (teacher_image_forward, teacher_text_forward, student_image_forward,   # noqa: F401
                        student_text_forward, clip_forward)

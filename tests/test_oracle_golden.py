@@ -185,3 +185,33 @@ def test_loss_components(golden_dir, case):
     for k in ('si', 'st'):
         ref = g[f'{case}.grad.{k}']
         np.testing.assert_allclose(e[k].grad.numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+
+
+def test_metrics_known_answers():
+    """validation metrics restatement (oracle/metrics.py) on hand-computable cases: a permutation structure fixes every
+    rank, and the diagonal scores follow from the logits in closed form."""
+    from oracle import metrics as om
+    n = 8
+    # one-hot rows scaled arbitrarily (norm_and_logits must remove the scale); row i matches caption i exactly
+    img = torch.eye(n) * torch.arange(1, n + 1)[:, None].float()
+    txt = torch.eye(n) * 3.0
+    m = om.retrieval_metrics(img, txt, k_list=(1, 3))
+    assert m['acc_top1'].item() == 1.0 and m['acc_top3'].item() == 1.0
+    assert m['ranks'].tolist() == [0] * n
+    assert abs(m['mean_score'].item() - 1.0) < 1e-12
+    # logits row = (1, 0, ..., 0) up to position: softmax diagonal = e / (e + n - 1)
+    e = float(np.e)
+    assert abs(m['softmax_mean_score'].item() - e / (e + n - 1)) < 1e-12
+    # rank structure: caption j scores c - |i - j| * step against image i, shifted so that image i's best caption is i + s
+    ang = torch.linspace(0.0, 1.0, n)
+    base = torch.stack([torch.cos(ang), torch.sin(ang)], 1)               # unit vectors on an arc, angle gap 1/7
+    shift = 2
+    m2 = om.retrieval_metrics(base, base.roll(-shift, 0), k_list=(1, 3, 5))
+    # image i best matches the caption equal to itself, which sits at index i - shift: for i >= shift the label caption i
+    # (vector i + shift) is `shift` steps away: captions at distance < shift on both sides beat it
+    lg, _ = om.norm_and_logits(base.double(), base.roll(-shift, 0).double())
+    want = (lg > torch.diagonal(lg)[:, None]).sum(1)
+    assert m2['ranks'].tolist() == want.tolist()
+    for k in (1, 3, 5):
+        assert abs(m2[f'acc_top{k}'].item() - (want < k).double().mean().item()) < 1e-12
+    assert m2['acc_top1'].item() < m2['acc_top3'].item() <= m2['acc_top5'].item()

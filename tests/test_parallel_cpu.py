@@ -124,3 +124,37 @@ def test_sharded_loss_equals_reference_ddp_semantics():
     # per-sample tower terms are shard-additive; cos_diff uses per-shard negatives, so the full-batch loss differs
     assert abs(0.5 * (l0 + l1) - lf) > 1e-6
     assert gi0.shape == (4, 32) and gi1.shape == (4, 32)
+
+
+def _gather_rows_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from distillclip_amd.metrics import gather_rows
+    x = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank
+    q.put((rank, gather_rows(x).clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_gather_rows_world2():
+    """validation_step's all_gather of the representations (reference dual_distill_model.py:141-146): rank-major rows,
+    identical on every rank, so each rank's validation_epoch_end sees the whole validation set"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = torch.arange(6, dtype=torch.float32).reshape(3, 2)
+    for _, g in res:
+        assert torch.equal(g, torch.cat([base, base + 100]))
+
+
+def test_gather_rows_is_identity_without_process_group():
+    from distillclip_amd.metrics import gather_rows
+    x = torch.randn(4, 8)
+    assert gather_rows(x) is x
