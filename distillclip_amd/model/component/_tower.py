@@ -43,6 +43,8 @@ class HipTower:
         self._ws_key = None
         self._saved_batch = None
         self.bwd_done = None
+        # load_state_dict copies into the flat buffer in place: frozen towers must re-cast their bf16 weight cache afterwards
+        module.register_load_state_dict_post_hook(lambda m, incompatible: setattr(self, 'wcache_dirty', True))
 
     def __del__(self):
         try:

@@ -63,6 +63,70 @@ class FusedAdamW:
             tw.wcache_dirty = True
 
 
+    # ---- torch.optim.AdamW-compatible (de)serialisation: what a Lightning checkpoint stores under 'optimizer_states' ----
+    def _slots(self, params=None):
+        """[(tower, offset, numel, shape)] of the trainable parameters, in `params` order (default: tower order)."""
+        where = {}
+        for tw in self.towers:
+            if tw.flat is None:
+                continue
+            live = [p for p in tw._params() if p is not None]
+            for p, off in zip(live, tw._offsets):
+                if p.requires_grad:
+                    where[p.data_ptr()] = (tw, off, p.numel(), tuple(p.shape))
+        if params is None:
+            return list(where.values())
+        out = []
+        for p in params:
+            if not p.requires_grad:
+                continue
+            if p.data_ptr() not in where:
+                raise ValueError('FusedAdamW.state_dict: a trainable parameter is not a view of a tower buffer')
+            out.append(where[p.data_ptr()])
+        return out
+
+    def state_dict(self, params=None):
+        """`params`: the iteration order torch.optim.AdamW would have been built with (reference distil_model.py:161,
+        dual_distill_model.py:195: filter(requires_grad, self.parameters())); default = canonical tower order."""
+        slots = self._slots(params)
+        state = {}
+        for i, (tw, off, n, shape) in enumerate(slots):
+            if id(tw) in self._state:
+                m, v = self._state[id(tw)]
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': m[off:off + n].view(shape).clone(),
+                            'exp_avg_sq': v[off:off + n].view(shape).clone()}
+        group = {'lr': self.lr, 'initial_lr': self.base_lr, 'betas': tuple(self.betas), 'eps': self.eps,
+                 'weight_decay': self.weight_decay, 'amsgrad': False, 'maximize': False, 'foreach': None,
+                 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(slots)))}
+        return {'state': state, 'param_groups': [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd, params=None):
+        slots = self._slots(params)
+        group = sd['param_groups'][0]
+        if len(group['params']) != len(slots):
+            raise ValueError(f"FusedAdamW.load_state_dict: {len(group['params'])} saved parameters, {len(slots)} trainable here")
+        self.lr = group['lr']
+        self.base_lr = group.get('initial_lr', self.base_lr)
+        self.betas, self.eps, self.weight_decay = tuple(group['betas']), group['eps'], group['weight_decay']
+        steps = set()
+        for i, (tw, off, n, shape) in enumerate(slots):
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            if id(tw) not in self._state:
+                self._state[id(tw)] = (torch.zeros_like(tw.flat), torch.zeros_like(tw.flat))
+            m, v = self._state[id(tw)]
+            if tuple(st['exp_avg'].shape) != shape:
+                raise ValueError(f"FusedAdamW.load_state_dict: parameter {i} has shape {shape}, saved {tuple(st['exp_avg'].shape)}")
+            m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('FusedAdamW.load_state_dict: parameters with different step counts (one fused step counter here)')
+        self.step_count = steps.pop() if steps else 0
+
+
 class EpochCosineSchedule:
     """lr = base_lr * cosine_with_warmup(epoch): stepped once per epoch like the reference's Lightning default."""
 
@@ -76,3 +140,10 @@ class EpochCosineSchedule:
 
     def get_last_lr(self):
         return [self.opt.lr]
+
+    def state_dict(self):
+        return {'last_epoch': self.epoch, 'warm_steps': self.warm, 'total_steps': self.total, '_last_lr': [self.opt.lr]}
+
+    def load_state_dict(self, sd):
+        self.epoch = sd['last_epoch']
+        self.opt.lr = self.opt.base_lr * cosine_with_warmup(self.epoch, self.warm, self.total)

@@ -1,0 +1,149 @@
+"""Checkpoint layout + resume (reference dual_distill_model.py:22-38 load_weight, Lightning's
+ModelCheckpoint layout, distil_model.py:160-169 optimizer construction)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distillclip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+S_IMG = dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4,
+             mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+S_TXT = dict(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2,
+             mlp_ratio=4.0, qkv_bias=False, repeated_times=2, use_transform=True)
+T = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def _teacher_sd(seed):
+    tsd = synth.teacher_image_state(seed, 128, 2, 8, 32, 64)
+    tsd.update(synth.teacher_text_state(seed, 128, 2, 13, 97, 64))
+    return T(tsd)
+
+
+def _dual(seed, lr=1e-3):
+    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    s_img, s_txt = RepeatVisionTransformer(**S_IMG), RepeatTextTransformer(**S_TXT)
+    s_img.load_state_dict(T(synth.student_image_state(seed, **S_IMG)))
+    s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT)))
+    m = DualDistillModel(s_img, s_txt, dict(loss_name=['out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1}),
+                         warm_steps=2, total_steps=10, weight_decay=1e-2, lr=lr, download_root='.',
+                         teacher_state_dict=_teacher_sd(7)).cuda()
+    (opt,), (sched,) = m.configure_optimizers()
+    return m, opt, sched
+
+
+def _batch(i, B=6):
+    return [torch.from_numpy(synth.images(100 + i, B, 32)).cuda(), torch.from_numpy(synth.captions(100 + i, B, 13, 97, 3, 9)).cuda()]
+
+
+def _step(m, opt, i):
+    opt.zero_grad()
+    loss = m.training_step(_batch(i))
+    m.backward_and_sync(loss)
+    opt.step()
+    return loss.item()
+
+
+def test_save_resume_continues_the_run(tmp_path):
+    from distillclip_amd.checkpoint import save_checkpoint, load_checkpoint
+    m, opt, sched = _dual(3)
+    for i in range(2):
+        _step(m, opt, i)
+    sched.step()
+    path = os.path.join(tmp_path, 'epoch0.ckpt')
+    save_checkpoint(path, m, opt, sched, epoch=1, global_step=2)
+    l3 = _step(m, opt, 2)
+    want = {k: v.detach().clone() for k, v in m.student.state_dict().items()}
+
+    m2, opt2, sched2 = _dual(99)                       # different initial weights: everything must come from the file
+    epoch, gstep = load_checkpoint(path, m2, opt2, sched2)
+    assert (epoch, gstep) == (1, 2) and m2.current_epoch == 1
+    assert opt2.step_count == 2 and abs(opt2.lr - opt.lr) < 1e-12 and sched2.epoch == 1
+    l3b = _step(m2, opt2, 2)
+    assert abs(l3 - l3b) <= 1e-5 * abs(l3), (l3, l3b)
+    got = m2.student.state_dict()
+    for k, v in want.items():
+        err = (got[k] - v).norm().item() / (v.norm().item() + 1e-12)
+        assert err < 2e-4, (k, err)                      # wgrad accumulates with f32 atomics: not bit-reproducible
+
+
+def test_layout_is_the_references(tmp_path):
+    """keys carry Lightning's 'student.' / 'teacher.' prefixes; the optimizer entry loads into torch.optim.AdamW built the
+    way the reference builds it, and that AdamW then takes the same step as the fused kernel"""
+    from distillclip_amd.checkpoint import checkpoint_dict, student_state_dict, trainable_parameters
+    m, opt, sched = _dual(5)
+    _step(m, opt, 0)
+    ck = checkpoint_dict(m, opt, sched, epoch=0, global_step=1)
+    buf = io.BytesIO()
+    torch.save(ck, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location='cpu')             # weights_only load: plain containers and tensors only
+    keys = list(ck['state_dict'])
+    assert all(k.startswith(('student.', 'teacher.')) for k in keys)
+    assert 'student.image_encoder.blocks.0.block.attn.conv_l.instances.1.weight' in keys
+    assert 'student.text_encoder.patch_embed.weight' in keys
+    assert 'teacher.image_encoder.visual.transformer.resblocks.1.attn.in_proj_weight' in keys
+    assert 'teacher.text_encoder.token_embedding.weight' in keys
+    stu = student_state_dict(ck)
+    assert set(stu) == {k for k in m.student.state_dict()}
+    # torch AdamW over CPU copies of the trainable parameters, in the reference's order
+    params = trainable_parameters(m)
+    cpu = [torch.nn.Parameter(p.detach().cpu().clone()) for p in params]
+    ref = torch.optim.AdamW(cpu, lr=m.hparams.lr, weight_decay=m.hparams.weight_decay)
+    ref.load_state_dict(ck['optimizer_states'][0])
+    assert len(ref.state) == len(cpu)
+    # next step with identical gradients on both sides
+    opt.zero_grad()
+    loss = m.training_step(_batch(1))
+    m.backward_and_sync(loss)
+    for c, p in zip(cpu, params):
+        c.grad = p.grad.detach().cpu().clone()
+    opt.step()
+    ref.step()
+    for c, p in zip(cpu, params):
+        err = (p.detach().cpu() - c.detach()).abs().max().item()
+        assert err <= 1e-6 + 1e-5 * c.detach().abs().max().item(), err
+
+
+def test_stage1_files_feed_load_weight(tmp_path):
+    """reference l_clip.yaml load_path: two one-tower stage-1 checkpoints -> dual students (dual_distill_model.py:22-38)"""
+    from distillclip_amd.checkpoint import save_checkpoint
+    from distillclip_amd.model import DistillModel
+    from distillclip_amd.model.dual_distill_model import load_weight
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    tsd = _teacher_sd(7)
+    paths = {}
+    for kind, cls, cfg, state in (('image', RepeatVisionTransformer, S_IMG, synth.student_image_state),
+                                  ('text', RepeatTextTransformer, S_TXT, synth.student_text_state)):
+        stu = cls(**cfg)
+        stu.load_state_dict(T(state(11, **cfg)))
+        one = DistillModel(stu, dict(loss_name=['out_cos']), '.', model_type=kind, teacher_state_dict=tsd)
+        paths[kind] = os.path.join(tmp_path, f'{kind}.ckpt')
+        save_checkpoint(paths[kind], one)
+    a, b = RepeatVisionTransformer(**S_IMG), RepeatTextTransformer(**S_TXT)
+    a, b = load_weight(a, b, paths)
+    for k, v in T(synth.student_image_state(11, **S_IMG)).items():
+        assert torch.equal(a.state_dict()[k], v)
+    for k, v in T(synth.student_text_state(11, **S_TXT)).items():
+        assert torch.equal(b.state_dict()[k], v)
+    with pytest.raises(ValueError):
+        load_weight(a, b, {'image': None, 'text': paths['text']})
+
+
+def test_frozen_teacher_reload_refreshes_weight_cache():
+    """load_state_dict after a forward must reach the bf16 weight cache of a frozen tower"""
+    m, opt, _ = _dual(3)
+    batch = _batch(0)
+    with torch.no_grad():
+        _, t0 = m.forward(batch)
+        r0 = t0.visual_output.last_representation.clone()
+        sd = {k: v.clone() for k, v in m.teacher.state_dict().items()}
+        sd['image_encoder.visual.proj'] = sd['image_encoder.visual.proj'] * 2.0
+        m.teacher.load_state_dict(sd)
+        _, t1 = m.forward(batch)
+    assert torch.allclose(t1.visual_output.last_representation, 2.0 * r0, rtol=2e-2, atol=1e-4)
