@@ -1,0 +1,209 @@
+// Training image transform after decode / resize / crop, on the GPU (gfx950):
+//     RandAugment(num_ops) -> ToTensor -> Normalize        uint8 [B,H,W,3]  ->  f32 [B,3,H,W]
+//
+//   reference: data/component/ms_coco.py:15-26 (the transform chain), rand_augment.py:10-87 (_apply_op), :128-166 (op table
+//   and the per-image loop), utils.py:11-12 (CLIP mean / std).  The reference runs the ops on PIL images (torchvision's
+//   functional_pil path); this kernel reproduces Pillow's pixel arithmetic bit for bit (oracle/augment.py states each rule and
+//   tests/test_augment_cpu.py pins the rules against the real Pillow):
+//     geometric ops   Image.transform(AFFINE, NEAREST): 16.16 fixed-point source coordinates (Geometry.c affine_fixed);
+//                     unit-scale translations take Pillow's ImagingScaleAffine path = an integer shift
+//     Brightness / Contrast / Sharpness   ImageEnhance: Image.blend(degenerate, image, factor) in float32, truncating inside
+//                     [0,1], clipping outside; degenerate = black / rounded mean luma (16.16 ITU-R 601) / 3x3 SMOOTH filter
+//     Posterize       bit mask ;  AutoContrast / Equalize   ImageOps per-channel histogram look-up tables
+// One workgroup per image walks the image's op list; stages ping-pong between two byte images in the workspace (150 KiB
+// each at 224 px: they live in L2).  HBM-bound byte work: no MFMA, floating-point contraction is switched off for this file so
+// that no fused multiply-add changes a rounding Pillow's scalar C code does not have.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+// Pillow's scalar C code rounds every product and every sum: no fused multiply-add may be formed in this file (HIP's
+// __fmul_rn / __fadd_rn are plain operators compiled under -ffp-contract=fast, so the file uses its own helpers).
+#pragma clang fp contract(off)
+
+namespace {
+
+// individually rounded IEEE operations (defined after the pragma above, so that they carry no `contract` flag)
+__device__ __forceinline__ float mul_r(float x, float y) { return x * y; }
+__device__ __forceinline__ float add_r(float x, float y) { return x + y; }
+__device__ __forceinline__ float sub_r(float x, float y) { return x - y; }
+__device__ __forceinline__ float div_r(float x, float y) { return x / y; }
+__device__ __forceinline__ double dmul_r(double x, double y) { return x * y; }
+__device__ __forceinline__ double dadd_r(double x, double y) { return x + y; }
+
+enum { OP_IDENTITY = 0, OP_AFFINE = 1, OP_SHIFT = 2, OP_BRIGHTNESS = 3, OP_CONTRAST = 4, OP_SHARPNESS = 5, OP_POSTERIZE = 6,
+       OP_AUTOCONTRAST = 7, OP_EQUALIZE = 8, OP_COUNT = 9 };
+
+struct AugArgs {
+    const uint8_t* in; const dclip_aug_op* ops; int num_ops;
+    int B, H, W;
+    float mean[3], stdv[3];
+    float* out; uint8_t* aug_out;
+    uint8_t* ws;
+};
+
+__device__ __forceinline__ uint8_t blend_px(int d, int v, float alpha, bool inside) {
+    const float t = add_r((float)d, mul_r(alpha, (float)(v - d)));
+    if (inside) return (uint8_t)t;
+    if (t <= 0.f) return 0;
+    if (t >= 255.f) return 255;
+    return (uint8_t)t;
+}
+
+__global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
+    __shared__ unsigned hist[3][256];
+    __shared__ uint8_t lut[3][256];
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const int H = a.H, W = a.W, npix = H * W, nbytes = npix * 3;
+    const uint8_t* src = a.in + (int64_t)img * nbytes;
+    uint8_t* buf0 = a.ws + (int64_t)img * 2 * nbytes;
+    uint8_t* buf1 = buf0 + nbytes;
+    uint8_t* dst = buf0;
+    for (int s = 0; s < a.num_ops; ++s) {
+        const dclip_aug_op op = a.ops[(int64_t)img * a.num_ops + s];
+        if (op.op == OP_IDENTITY) continue;
+        if (op.op == OP_AFFINE || op.op == OP_SHIFT) {
+            for (int p = tid; p < npix; p += 256) {
+                const int y = p / W, x = p - y * W;
+                int xin, yin;
+                if (op.op == OP_AFFINE) {
+                    xin = (op.c[2] + op.c[1] * y + op.c[0] * x) >> 16;
+                    yin = (op.c[5] + op.c[4] * y + op.c[3] * x) >> 16;
+                } else {
+                    xin = x + op.c[0];
+                    yin = y + op.c[1];
+                }
+                uint8_t r = 0, g = 0, b = 0;
+                if (xin >= 0 && xin < W && yin >= 0 && yin < H) {
+                    const uint8_t* q = src + (yin * W + xin) * 3;
+                    r = q[0]; g = q[1]; b = q[2];
+                }
+                dst[p * 3 + 0] = r; dst[p * 3 + 1] = g; dst[p * 3 + 2] = b;
+            }
+        } else if (op.op == OP_BRIGHTNESS || op.op == OP_CONTRAST) {
+            int deg = 0;
+            if (op.op == OP_CONTRAST) {
+                unsigned long long sum = 0;
+                for (int p = tid; p < npix; p += 256) {
+                    const uint8_t* q = src + p * 3;
+                    sum += (unsigned)((q[0] * 19595 + q[1] * 38470 + q[2] * 7471 + 0x8000) >> 16);
+                }
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = sum;
+                __syncthreads();
+                sum = (red[0] + red[1]) + (red[2] + red[3]);
+                deg = (int)((double)sum / (double)npix + 0.5);       // int(ImageStat.Stat(L).mean[0] + 0.5)
+            }
+            const bool inside = op.f >= 0.f && op.f <= 1.f;
+            for (int i = tid; i < nbytes; i += 256) dst[i] = blend_px(deg, src[i], op.f, inside);
+        } else if (op.op == OP_SHARPNESS) {
+            const float k1 = 1.f / 13.f, k5 = 5.f / 13.f;               // (FLOAT32) kernel[i] / divisor, as Filter.c stores them
+            const bool inside = op.f >= 0.f && op.f <= 1.f;
+            for (int i = tid; i < nbytes; i += 256) {
+                const int p = i / 3, ch = i - p * 3;
+                const int y = p / W, x = p - y * W;
+                const int v = src[i];
+                int sm = v;                                              // one-pixel border: copied
+                if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+                    float ss = 0.5f;
+#pragma unroll
+                    for (int dy = 1; dy >= -1; --dy) {
+                        const uint8_t* q = src + ((y + dy) * W + x) * 3 + ch;
+                        const float kc = dy == 0 ? k5 : k1;
+                        const float row = add_r(add_r(mul_r((float)q[-3], k1), mul_r((float)q[0], kc)),
+                                                    mul_r((float)q[3], k1));
+                        ss = add_r(ss, row);
+                    }
+                    const int t = (int)ss;
+                    sm = t < 0 ? 0 : (t > 255 ? 255 : t);
+                }
+                dst[i] = blend_px(sm, v, op.f, inside);
+            }
+        } else if (op.op == OP_POSTERIZE) {
+            const uint8_t mask = (uint8_t)op.c[0];
+            for (int i = tid; i < nbytes; i += 256) dst[i] = src[i] & mask;
+        } else {                                                         // OP_AUTOCONTRAST / OP_EQUALIZE
+            __syncthreads();
+            for (int i = tid; i < 768; i += 256) (&hist[0][0])[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < nbytes; i += 256) atomicAdd(&hist[i % 3][src[i]], 1u);
+            __syncthreads();
+            if (op.op == OP_AUTOCONTRAST) {
+                for (int ch = 0; ch < 3; ++ch) {
+                    int lo = 0, hi = 255;
+                    while (lo < 256 && hist[ch][lo] == 0u) ++lo;
+                    while (hi >= 0 && hist[ch][hi] == 0u) --hi;
+                    int v = tid;
+                    if (hi > lo) {
+                        const double scale = 255.0 / (double)(hi - lo);
+                        const double offset = -(double)lo * scale;
+                        const double t = dadd_r(dmul_r((double)tid, scale), offset);
+                        v = (int)t;
+                        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    }
+                    lut[ch][tid] = (uint8_t)v;
+                }
+            } else {
+                if (tid < 3) {
+                    const int ch = tid;
+                    long long total = 0, last = 0;
+                    int nz = 0;
+                    for (int i = 0; i < 256; ++i)
+                        if (hist[ch][i]) { total += hist[ch][i]; last = hist[ch][i]; ++nz; }
+                    const long long step = nz <= 1 ? 0 : (total - last) / 255;
+                    long long n = step / 2;
+                    for (int i = 0; i < 256; ++i) {
+                        long long v = step ? n / step : i;
+                        lut[ch][i] = (uint8_t)(v > 255 ? 255 : v);
+                        n += hist[ch][i];
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < nbytes; i += 256) dst[i] = lut[i % 3][src[i]];
+        }
+        __threadfence_block();
+        __syncthreads();                                                // the next stage reads what other lanes wrote
+        src = dst;
+        dst = dst == buf0 ? buf1 : buf0;
+    }
+    // ToTensor + Normalize: float32(v) / 255, - mean, / std  (IEEE divisions, as torch's float32 kernels)
+    float* o = a.out + (int64_t)img * nbytes;
+    for (int i = tid; i < nbytes; i += 256) {
+        const int ch = i / npix, p = i - ch * npix;
+        const uint8_t v = src[p * 3 + ch];
+        o[i] = div_r(sub_r(div_r((float)v, 255.f), a.mean[ch]), a.stdv[ch]);
+    }
+    if (a.aug_out) {
+        uint8_t* ao = a.aug_out + (int64_t)img * nbytes;
+        for (int i = tid; i < nbytes; i += 256) ao[i] = src[i];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dclip_augment_workspace(int64_t B, int64_t H, int64_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * 2 * (size_t)H * (size_t)W * 3;
+}
+
+extern "C" int dclip_augment_normalize(const uint8_t* images, int64_t B, int64_t H, int64_t W, const dclip_aug_op* ops,
+                                       int num_ops, const float* mean3, const float* std3, float* out, uint8_t* aug_out,
+                                       void* workspace, size_t ws_bytes, void* stream) {
+    DCLIP_REQUIRE(images && out && mean3 && std3, "dclip_augment_normalize: null operand");
+    DCLIP_REQUIRE(B > 0 && H >= 3 && W >= 3 && H <= 4096 && W <= 4096, "dclip_augment_normalize: need B > 0 and 3 <= H, W <= 4096 (B=%ld H=%ld W=%ld)",
+                  (long)B, (long)H, (long)W);
+    DCLIP_REQUIRE(num_ops >= 0 && num_ops <= 16 && (num_ops == 0 || ops), "dclip_augment_normalize: 0 <= num_ops <= 16 with an op table");
+    DCLIP_REQUIRE(num_ops == 0 || (workspace && ws_bytes >= dclip_augment_workspace(B, H, W)),
+                  "dclip_augment_normalize: workspace too small (%zu < %zu)", ws_bytes, dclip_augment_workspace(B, H, W));
+    DCLIP_REQUIRE(B < (1LL << 24), "dclip_augment_normalize: batch too large");
+    AugArgs a;
+    a.in = images; a.ops = ops; a.num_ops = num_ops; a.B = (int)B; a.H = (int)H; a.W = (int)W;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+    a.out = out; a.aug_out = aug_out; a.ws = (uint8_t*)workspace;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    return dclip_check_launch("dclip_augment_normalize");
+}

@@ -163,6 +163,27 @@ int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_tx
                        const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt, void* workspace,
                        size_t ws_bytes, void* stream);
 /*
+ * Training image transform after decode / resize / crop: RandAugment -> ToTensor -> Normalize.
+ *   reference: data/component/ms_coco.py:15-26 (transform chain), rand_augment.py:10-87 (_apply_op), :128-166 (op table,
+ *   per-image loop), utils.py:11-12 (CLIP mean / std).  Pixel results equal Pillow's (the reference's backend) bit for bit.
+ * images: uint8 [B,H,W,3] device (RGB, what np.asarray(PIL image) holds); ops: device [B, num_ops] records, applied in order:
+ *   op 0 identity ; 1 nearest affine, c[0..5] = Pillow's 16.16 fixed-point coefficients (a0 a1 a2 a3 a4 a5 of Geometry.c
+ *   affine_fixed) ; 2 integer shift, source = (x + c[0], y + c[1]) ; 3 brightness, 4 contrast, 5 sharpness with enhancement
+ *   factor f ; 6 posterize with byte mask c[0] ; 7 autocontrast ; 8 equalize.   (distillclip_amd/augment.py builds the
+ *   records from RandAugment's (op name, magnitude) draws.)
+ * mean3 / std3: HOST float[3].  out: f32 [B,3,H,W] = (byte / 255 - mean) / std.  aug_out (nullable): the augmented bytes
+ * [B,H,W,3].  workspace: dclip_augment_workspace(B,H,W) bytes (two byte images per sample), unused when num_ops == 0.
+ */
+typedef struct dclip_aug_op {
+    int32_t op;
+    int32_t c[6];
+    float f;
+} dclip_aug_op;
+size_t dclip_augment_workspace(int64_t B, int64_t H, int64_t W);
+int dclip_augment_normalize(const uint8_t* images, int64_t B, int64_t H, int64_t W, const dclip_aug_op* ops, int num_ops,
+                            const float* mean3, const float* std3, float* out, uint8_t* aug_out, void* workspace,
+                            size_t ws_bytes, void* stream);
+/*
  * Validation retrieval metrics of one image -> caption logits matrix, without materialising it.
  *   reference: dual_distill_model.py:271-275 (norm_and_logits), :204-212 (log_diag_score), :220-224 (log_acc with
  *   torchmetrics accuracy(top_k = k) against labels arange(n)), k_list :87 ; distil_model.py:171-191, :224-231.
