@@ -213,3 +213,122 @@ class EvalTransformGPU:
 
     def __call__(self, images_u8):
         return normalize_batch(images_u8, None, self.mean, self.std)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resize(size) + CenterCrop(size) on the GPU (reference ms_coco.py:16-17,23-24): Pillow's antialiased bilinear resample
+# ---------------------------------------------------------------------------------------------------------------------
+RESIZE_DESC_DTYPE = np.dtype([('src_offset', '<i8'), ('table_offset', '<i8'), ('temp_offset', '<i8'), ('height', '<i4'),
+                              ('width', '<i4'), ('row0', '<i4'), ('nrows', '<i4'), ('ksize_h', '<i4'), ('ksize_v', '<i4')])
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _resample_coeffs(in_size, out_size):
+    """libImaging Resample.c precompute_coeffs (triangle filter, support 1) + normalize_coeffs_8bpc, vectorised over the
+    output index with the same double-precision operation order -> (bounds [out, 2], weights [out, ksize]) int32"""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    j = np.arange(ksize, dtype=np.int64)[None, :]
+    v = np.abs((((j + xmin[:, None]) - center[:, None]) + 0.5) * ss)
+    w = np.where(v < 1.0, 1.0 - v, 0.0)
+    w = np.where(j < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for c in range(ksize):                                   # the C loop accumulates in index order
+        ww = ww + w[:, c]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    kk = (0.5 + w * float(1 << _PRECISION_BITS)).astype(np.int64).astype(np.int32)
+    kk = np.where(j < xmax[:, None], kk, 0).astype(np.int32)
+    return np.stack([xmin, xmax], 1).astype(np.int32), kk
+
+
+_TABLE_CACHE = {}
+
+
+def resample_tables(height, width, size):
+    """-> (int32 table block [hb | hk | vb | vk], row0, nrows, ksize_h, ksize_v) for one source size (cached)"""
+    key = (height, width, size)
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    if width <= height:                                      # torchvision Resize(int): shorter side -> size
+        nw, nh = size, int(size * height / width)
+    else:
+        nw, nh = int(size * width / height), size
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    hb, hk = _resample_coeffs(width, nw)
+    vb, vk = _resample_coeffs(height, nh)
+    hb, hk, vb, vk = hb[left:left + size], hk[left:left + size], vb[top:top + size].copy(), vk[top:top + size]
+    row0 = int(vb[0, 0])
+    nrows = int(vb[-1, 0] + vb[-1, 1]) - row0
+    vb[:, 0] -= row0
+    block = np.concatenate([hb.reshape(-1), hk.reshape(-1), vb.reshape(-1), vk.reshape(-1)]).astype(np.int32)
+    out = (block, row0, nrows, hk.shape[1], vk.shape[1])
+    if len(_TABLE_CACHE) < 4096:
+        _TABLE_CACHE[key] = out
+    return out
+
+
+class ResizeCenterCropGPU:
+    """transforms.Resize(size) + transforms.CenterCrop(size) of decoded images (list of uint8 [h, w, 3] numpy arrays or CPU
+    tensors, any sizes) -> uint8 [B, size, size, 3] on the GPU, equal to the PIL result byte for byte."""
+
+    def __init__(self, size=224):
+        self.size = size
+        self._pinned = None                      # grow-only pinned staging buffer (a fresh pin per batch costs more than the copy)
+        self._pin_free = None                    # event after which the staging buffer may be overwritten
+
+    def __call__(self, images, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('distillclip_amd has no CPU path: ResizeCenterCropGPU needs a CUDA (HIP) device')
+        dev = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        S, B = self.size, len(images)
+        if B == 0:
+            raise ValueError('ResizeCenterCropGPU: empty batch')
+        desc = np.zeros(B, dtype=RESIZE_DESC_DTYPE)
+        blocks, table_pos, src_pos, temp_pos = {}, 0, 0, 0
+        table_list = []
+        arrs = []
+        for i, im in enumerate(images):
+            a = im.numpy() if torch.is_tensor(im) else np.asarray(im)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError(f'image {i}: expected uint8 [h, w, 3], got {a.dtype} {a.shape}')
+            h, w = a.shape[:2]
+            if min(h, w) < 1 or max(h, w) > 16384:
+                raise ValueError(f'image {i}: unsupported size {h} x {w}')
+            block, row0, nrows, ksh, ksv = resample_tables(h, w, S)
+            if (h, w) not in blocks:                          # images of one size share a table block
+                blocks[(h, w)] = table_pos
+                table_list.append(block)
+                table_pos += block.size
+            desc[i] = (src_pos, blocks[(h, w)], temp_pos, h, w, row0, nrows, ksh, ksv)
+            arrs.append(np.ascontiguousarray(a).reshape(-1))
+            src_pos += (a.size + 15) // 16 * 16
+            temp_pos += (nrows * S * 3 + 15) // 16 * 16
+        if self._pinned is None or self._pinned.numel() < src_pos:
+            self._pinned = torch.empty(int(src_pos * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        elif self._pin_free is not None:
+            self._pin_free.synchronize()
+        packed = self._pinned[:src_pos]
+        pv = packed.numpy()
+        for i, flat in enumerate(arrs):
+            o = int(desc[i]['src_offset'])
+            pv[o:o + flat.size] = flat
+        tables = torch.from_numpy(np.concatenate(table_list))
+        d_packed = packed.to(dev, non_blocking=True)
+        self._pin_free = torch.cuda.Event()
+        self._pin_free.record(torch.cuda.current_stream(dev))
+        d_tables = tables.to(dev, non_blocking=True)
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(B, -1)).to(dev, non_blocking=True)
+        ws = torch.empty(max(temp_pos, 16), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, S, S, 3), dtype=torch.uint8, device=dev)
+        lib().dclip_resize_center_crop(d_packed.data_ptr(), d_desc.data_ptr(), d_tables.data_ptr(), B, S, out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        for t in (d_packed, d_tables, d_desc):
+            t.record_stream(torch.cuda.current_stream())
+        return out

@@ -207,3 +207,75 @@ extern "C" int dclip_augment_normalize(const uint8_t* images, int64_t B, int64_t
     hipLaunchKernelGGL(augment_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
     return dclip_check_launch("dclip_augment_normalize");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Resize(S) + CenterCrop(S) of decoded images of mixed sizes: Pillow's two-pass antialiased bilinear resample
+// (libImaging Resample.c: 8-bit pass results, 22-bit fixed-point coefficients), evaluated only on the crop window.
+//   reference: data/component/ms_coco.py:16-17,23-24 (transforms.Resize(224), transforms.CenterCrop(224) on PIL images)
+// The coefficient tables depend on the source size only; the host builds them in double precision exactly as
+// precompute_coeffs / normalize_coeffs_8bpc do (distillclip_amd/augment.py caches them per size).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ResizeArgs {
+    const uint8_t* packed; const dclip_resize_desc* desc; const int32_t* tables;
+    int S;
+    uint8_t* out; uint8_t* ws;
+};
+
+__device__ __forceinline__ uint8_t clip8_fixed(int v) {
+    v >>= 22;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void resize_crop_kernel(ResizeArgs a) {
+    const dclip_resize_desc d = a.desc[blockIdx.x];
+    const int S = a.S, H = d.height, W = d.width;
+    const uint8_t* src = a.packed + d.src_offset;
+    const int32_t* hb = a.tables + d.table_offset;
+    const int32_t* hk = hb + 2 * S;
+    const int32_t* vb = hk + (int64_t)S * d.ksize_h;
+    const int32_t* vk = vb + 2 * S;
+    uint8_t* temp = a.ws + d.temp_offset;
+    // horizontal pass over the source rows the crop window needs
+    const int n1 = d.nrows * S * 3;
+    for (int i = threadIdx.x; i < n1; i += 256) {
+        const int ch = i % 3, t = i / 3;
+        const int ox = t % S, r = t / S;
+        const int row = min(d.row0 + r, H - 1);
+        const int x0 = hb[ox * 2], n = hb[ox * 2 + 1];
+        const int32_t* k = hk + (int64_t)ox * d.ksize_h;
+        const uint8_t* p = src + ((int64_t)row * W) * 3 + ch;
+        int ss = 1 << 21;
+        for (int x = 0; x < n; ++x) ss += (int)p[min(x0 + x, W - 1) * 3] * k[x];
+        temp[i] = clip8_fixed(ss);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // vertical pass
+    uint8_t* o = a.out + (int64_t)blockIdx.x * S * S * 3;
+    const int n2 = S * S * 3;
+    for (int i = threadIdx.x; i < n2; i += 256) {
+        const int ch = i % 3, t = i / 3;
+        const int ox = t % S, oy = t / S;
+        const int y0 = vb[oy * 2], n = vb[oy * 2 + 1];
+        const int32_t* k = vk + (int64_t)oy * d.ksize_v;
+        int ss = 1 << 21;
+        for (int y = 0; y < n; ++y) ss += (int)temp[(min(y0 + y, d.nrows - 1) * S + ox) * 3 + ch] * k[y];
+        o[i] = clip8_fixed(ss);
+    }
+}
+
+}  // namespace
+
+extern "C" int dclip_resize_center_crop(const uint8_t* packed, const dclip_resize_desc* desc, const int32_t* tables, int64_t B,
+                                        int64_t S, uint8_t* out, void* workspace, size_t ws_bytes, void* stream) {
+    DCLIP_REQUIRE(packed && desc && tables && out && workspace, "dclip_resize_center_crop: null operand");
+    DCLIP_REQUIRE(B > 0 && B < (1LL << 24) && S >= 1 && S <= 4096, "dclip_resize_center_crop: need B > 0, 1 <= S <= 4096 (B=%ld S=%ld)",
+                  (long)B, (long)S);
+    DCLIP_REQUIRE(ws_bytes > 0, "dclip_resize_center_crop: empty workspace");
+    ResizeArgs a;
+    a.packed = packed; a.desc = desc; a.tables = tables; a.S = (int)S; a.out = out; a.ws = (uint8_t*)workspace;
+    hipLaunchKernelGGL(resize_crop_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    return dclip_check_launch("dclip_resize_center_crop");
+}

@@ -184,6 +184,27 @@ int dclip_augment_normalize(const uint8_t* images, int64_t B, int64_t H, int64_t
                             const float* mean3, const float* std3, float* out, uint8_t* aug_out, void* workspace,
                             size_t ws_bytes, void* stream);
 /*
+ * Resize(S) + CenterCrop(S) of a batch of decoded RGB images of mixed sizes, Pillow's antialiased
+ * bilinear two-pass resample evaluated on the crop window, bit-exact.
+ *   reference: data/component/ms_coco.py:16-17,23-24 (transforms.Resize(224) + transforms.CenterCrop(224) on PIL images).
+ * packed: device bytes, image i = uint8 [height, width, 3] at desc[i].src_offset.  desc: device [B].  tables: device int32;
+ * image i's block at tables + table_offset holds  hb[S][2] (first source column, count) , hk[S][ksize_h] (22-bit fixed-point
+ * weights) , vb[S][2] (first row relative to row0, count) , vk[S][ksize_v]  for the S crop columns / rows — the values
+ * Pillow's precompute_coeffs + normalize_coeffs_8bpc produce (distillclip_amd/augment.py:resample_tables builds and caches
+ * them per source size).  workspace: image i's horizontal-pass scratch uint8 [nrows, S, 3] at temp_offset.
+ * out: uint8 [B,S,S,3].
+ */
+typedef struct dclip_resize_desc {
+    int64_t src_offset;
+    int64_t table_offset;
+    int64_t temp_offset;
+    int32_t height, width;
+    int32_t row0, nrows;
+    int32_t ksize_h, ksize_v;
+} dclip_resize_desc;
+int dclip_resize_center_crop(const uint8_t* packed, const dclip_resize_desc* desc, const int32_t* tables, int64_t B, int64_t S,
+                             uint8_t* out, void* workspace, size_t ws_bytes, void* stream);
+/*
  * Validation retrieval metrics of one image -> caption logits matrix, without materialising it.
  *   reference: dual_distill_model.py:271-275 (norm_and_logits), :204-212 (log_diag_score), :220-224 (log_acc with
  *   torchmetrics accuracy(top_k = k) against labels arange(n)), k_list :87 ; distil_model.py:171-191, :224-231.

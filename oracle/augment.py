@@ -319,3 +319,78 @@ def np_rand_augment(arr, ops):
     for name, mag in ops:
         arr = np_apply_op(arr, name, mag)
     return arr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resize(size) + CenterCrop(size): numpy restatement of Pillow's two-pass antialiased bilinear resample (libImaging Resample.c:
+# precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc), restricted to the crop window
+# ---------------------------------------------------------------------------------------------------------------------
+PRECISION_BITS = 32 - 8 - 2
+
+
+def resize_target(w, h, size):
+    """torchvision Resize(int): shorter side -> size, longer side int(size * long / short)"""
+    if w <= h:
+        return size, int(size * h / w)
+    return int(size * w / h), size
+
+
+def resample_coeffs(in_size, out_size):
+    """-> (bounds int [out, 2] = (first source index, count), coefficients int [out, ksize]) of the triangle filter"""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        xmin = max(xmin, 0)
+        xmax = int(center + support + 0.5)
+        xmax = min(xmax, in_size) - xmin
+        w = np.empty(xmax, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            v = (x + xmin - center + 0.5) * ss
+            v = -v if v < 0 else v
+            w[x] = 1.0 - v if v < 1.0 else 0.0
+            ww += w[x]
+        if ww != 0.0:
+            w = w / ww
+        for x in range(xmax):
+            p = w[x] * (1 << PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + p) if w[x] < 0 else int(0.5 + p)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def np_resize_center_crop(arr, size=224):
+    """uint8 [h, w, 3] -> uint8 [size, size, 3] == np.asarray(pil_resize_center_crop(Image.fromarray(arr), size))"""
+    h, w = arr.shape[:2]
+    nw, nh = resize_target(w, h, size)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    hb, hk = resample_coeffs(w, nw)
+    vb, vk = resample_coeffs(h, nh)
+    hb, hk, vb, vk = hb[left:left + size], hk[left:left + size], vb[top:top + size], vk[top:top + size]
+    row0, row1 = int(vb[0, 0]), int(vb[-1, 0] + vb[-1, 1])
+    src = arr.astype(np.int64)
+    half = 1 << (PRECISION_BITS - 1)
+    if w != nw:
+        temp = np.empty((row1 - row0, size, 3), dtype=np.int64)
+        for ox in range(size):
+            x0, n = int(hb[ox, 0]), int(hb[ox, 1])
+            acc = half + (src[row0:row1, x0:x0 + n, :] * hk[ox, :n].astype(np.int64)[None, :, None]).sum(axis=1)
+            temp[:, ox, :] = np.clip(acc >> PRECISION_BITS, 0, 255)
+    else:
+        temp = src[row0:row1, left:left + size, :]
+    if h != nh:
+        out = np.empty((size, size, 3), dtype=np.int64)
+        for oy in range(size):
+            y0, n = int(vb[oy, 0]) - row0, int(vb[oy, 1])
+            acc = half + (temp[y0:y0 + n] * vk[oy, :n].astype(np.int64)[:, None, None]).sum(axis=0)
+            out[oy] = np.clip(acc >> PRECISION_BITS, 0, 255)
+    else:
+        out = temp[top - row0:top - row0 + size]
+    return out.astype(np.uint8)

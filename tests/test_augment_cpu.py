@@ -117,3 +117,33 @@ def test_bulk_draw_has_the_reference_distribution_and_records():
     frac_identity = float((codes == 0).mean())
     assert abs(frac_identity - 1 / 12) < 0.01
     assert abs(float((codes == 7).mean()) - 1 / 12) < 0.01 and abs(float((codes == 3).mean()) - 1 / 12) < 0.01
+
+
+SIZES = [(480, 640), (640, 480), (427, 640), (375, 500), (500, 333), (224, 300), (300, 224), (224, 224), (100, 80),
+         (80, 100), (1200, 1600), (225, 224), (2000, 230), (231, 229)]
+
+
+@pytest.mark.parametrize('h,w', SIZES)
+def test_resize_center_crop_restatement_equals_pillow(h, w):
+    """reference ms_coco.py:16-17: Resize(224) + CenterCrop(224) on PIL images (down- and up-scaling, both orientations)"""
+    from PIL import Image
+    arr = np.random.default_rng(h * 7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    want = np.asarray(A.pil_resize_center_crop(Image.fromarray(arr, 'RGB'), 224))
+    assert np.array_equal(want, A.np_resize_center_crop(arr, 224))
+
+
+@pytest.mark.parametrize('h,w', SIZES + [(3000, 4000)])
+def test_host_resample_tables_equal_the_oracle_coefficients(h, w):
+    """the product's vectorised table builder (distillclip_amd/augment.py) against the scalar restatement of Resample.c"""
+    from distillclip_amd.augment import resample_tables
+    block, row0, nrows, ksh, ksv = resample_tables(h, w, 224)
+    nw, nh = A.resize_target(w, h, 224)
+    left, top = int(round((nw - 224) / 2.0)), int(round((nh - 224) / 2.0))
+    hb, hk = A.resample_coeffs(w, nw)
+    vb, vk = A.resample_coeffs(h, nh)
+    hb, hk, vb, vk = hb[left:left + 224], hk[left:left + 224], vb[top:top + 224].copy(), vk[top:top + 224]
+    assert row0 == int(vb[0, 0]) and nrows == int(vb[-1, 0] + vb[-1, 1]) - row0
+    vb[:, 0] -= row0
+    want = np.concatenate([hb.reshape(-1), hk.reshape(-1), vb.reshape(-1), vk.reshape(-1)])
+    assert (ksh, ksv) == (hk.shape[1], vk.shape[1])
+    assert np.array_equal(block, want)

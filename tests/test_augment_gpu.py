@@ -130,3 +130,55 @@ def test_device_prefetcher_order_and_values():
         assert torch.equal(img, aug(u8.cuda(), generator=g2))
     with pytest.raises(ValueError):
         list(DevicePrefetcher([(torch.zeros(2, 3, 8, 8), torch.zeros(2, 77, dtype=torch.int64))], train=False))
+
+
+def test_resize_center_crop_mixed_sizes_bit_exact():
+    """reference ms_coco.py:16-17 on a ragged batch (COCO-like sizes, tiny and large images, up-scaling)"""
+    from PIL import Image
+    from distillclip_amd.augment import ResizeCenterCropGPU
+    sizes = [(480, 640), (640, 480), (427, 640), (375, 500), (500, 333), (224, 300), (300, 224), (224, 224), (100, 80),
+             (80, 100), (1200, 1600), (225, 224), (2000, 230), (231, 229), (480, 640), (1, 5), (7, 3)]
+    rng = np.random.default_rng(12)
+    imgs = []
+    for i, (h, w) in enumerate(sizes):
+        if i % 2:
+            y, x = np.mgrid[0:h, 0:w]
+            a = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) % 256)], -1).astype(np.uint8)
+        else:
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        imgs.append(a)
+    got = ResizeCenterCropGPU(224)(imgs).cpu().numpy()
+    assert got.shape == (len(sizes), 224, 224, 3)
+    for i, a in enumerate(imgs):
+        want = np.asarray(A.pil_resize_center_crop(Image.fromarray(a, 'RGB'), 224))
+        assert np.array_equal(got[i], want), (sizes[i], int((got[i] != want).sum()))
+    # 336 px variant (BASELINE.json configs[3]) and torch tensors as input
+    got336 = ResizeCenterCropGPU(336)([torch.from_numpy(imgs[0]), torch.from_numpy(imgs[10])]).cpu().numpy()
+    for g, a in zip(got336, (imgs[0], imgs[10])):
+        assert np.array_equal(g, np.asarray(A.pil_resize_center_crop(Image.fromarray(a, 'RGB'), 336)))
+
+
+def test_full_train_chain_decode_to_tensor_bit_exact():
+    """ms_coco.py:15-21 end to end on the GPU: Resize -> CenterCrop -> RandAugment(4) -> ToTensor -> Normalize"""
+    from PIL import Image
+    from distillclip_amd.augment import ResizeCenterCropGPU, RandAugmentGPU
+    rng = np.random.default_rng(3)
+    raw = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in [(480, 640), (333, 500), (640, 427), (256, 256)] * 4]
+    torch.manual_seed(5)
+    aug = RandAugmentGPU(num_ops=4)
+    plan = aug.draw(len(raw), 224, 224)
+    x = aug(ResizeCenterCropGPU(224)(raw), plan=plan).cpu().numpy()
+    for i, a in enumerate(raw):
+        img = np.asarray(A.pil_resize_center_crop(Image.fromarray(a, 'RGB'), 224))
+        want = A.to_tensor_normalize(A.pil_rand_augment(img, plan[i]))
+        assert np.array_equal(x[i], want), (i, plan[i])
+
+
+def test_resize_argument_errors():
+    from distillclip_amd.augment import ResizeCenterCropGPU
+    with pytest.raises(ValueError):
+        ResizeCenterCropGPU(224)([])
+    with pytest.raises(ValueError):
+        ResizeCenterCropGPU(224)([np.zeros((8, 8), dtype=np.uint8)])
+    with pytest.raises(ValueError):
+        ResizeCenterCropGPU(224)([np.zeros((8, 8, 3), dtype=np.float32)])

@@ -32,3 +32,15 @@ print(f'PIL chain (1 core): {tc*1e3:.2f} ms / image = {1/tc:,.0f} images/s per c
 t0 = time.time(); aug.records(aug.draw(B, 224, 224), 224, 224); print(f'host draw + records for {B} (reference RNG order): {(time.time()-t0)*1e3:.1f} ms')
 aug.draw_records(B, 224, 224)
 t0 = time.time(); aug.draw_records(B, 224, 224); print(f'host bulk draw_records for {B}: {(time.time()-t0)*1e3:.3f} ms')
+
+# resize + crop of a COCO-like ragged batch
+from PIL import Image
+from distillclip_amd.augment import ResizeCenterCropGPU
+raw = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in [(480, 640), (640, 480), (427, 640), (500, 375)] * (B // 4)]
+rc = ResizeCenterCropGPU(224)
+rc(raw); torch.cuda.synchronize()
+t0 = time.time(); y = rc(raw); torch.cuda.synchronize(); tg = time.time() - t0
+t0 = time.time()
+for a in raw[:32]: A.pil_resize_center_crop(Image.fromarray(a, 'RGB'), 224)
+tp = (time.time() - t0) / 32
+print(f'resize+crop: GPU path (pack + H2D + kernel, {sum(a.size for a in raw)/1e6:.0f} MB of pixels) {tg*1e3:.1f} ms / {B} images = {B/tg:,.0f} images/s ; PIL {tp*1e3:.2f} ms / image per core')
