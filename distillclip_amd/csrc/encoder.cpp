@@ -134,7 +134,10 @@ struct Work {
     // temporaries
     float* x0;                             // teacher image pre-ln_pre tokens
     float* G; bf16_t* Gb;                  // residual-stream gradient
-    bf16_t *dbig, *dh, *dqkv, *dR, *dS, *dout;
+    // gradients that are wgrad operands keep one slot per repeat: the R executions of a weight-shared block feed ONE
+    // wgrad GEMM over R * M rows (half the launches and half the f32 atomic traffic at R = 2)
+    bf16_t *gb_f2, *gb_pr;                 // [R][M, D] bf16 residual gradient as seen by fc2 / attn.proj
+    bf16_t *dbig, *dh, *dqkv, *dR, *dS, *dout;   // dbig [R][M, F], dqkv [R][M, 3D]
     float* tok_sum; float* demb;           // [N, D] ; compressed: [M, rank] f32
     size_t bytes;
 };
@@ -166,9 +169,18 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         ExecSave& s = w.ex[e];
         s.x_mid = b.take<float>(M * D);
         s.mean1 = b.take<float>(M); s.rstd1 = b.take<float>(M); s.mean2 = b.take<float>(M); s.rstd2 = b.take<float>(M);
-        s.h1 = b.take<bf16_t>(M * D); s.qkv = b.take<bf16_t>(M * 3 * D);
+        s.qkv = b.take<bf16_t>(M * 3 * D);
         s.S = b.take<float>(SN); s.P = b.take<bf16_t>(SN); s.Rm = p.c.head_mix ? b.take<bf16_t>(SN) : s.P;
-        s.ctx = b.take<bf16_t>(M * D); s.h2 = b.take<bf16_t>(M * D); s.z = b.take<bf16_t>(M * F); s.u = b.take<bf16_t>(M * F);
+        s.z = b.take<bf16_t>(M * F);
+        if (e % p.R == 0) {
+            // the wgrad operands (inputs of the four linears) of a block's R executions lie back to back: [R][M, .]
+            bf16_t* h1 = b.take<bf16_t>(p.R * M * D); bf16_t* ctx = b.take<bf16_t>(p.R * M * D);
+            bf16_t* h2 = b.take<bf16_t>(p.R * M * D); bf16_t* u = b.take<bf16_t>(p.R * M * F);
+            for (int r = 0; r < p.R; ++r) {
+                ExecSave& t = w.ex[e + r];
+                t.h1 = h1 + r * M * D; t.ctx = ctx + r * M * D; t.h2 = h2 + r * M * D; t.u = u + r * M * F;
+            }
+        }
     }
     w.patches = p.image ? b.take<bf16_t>(M * p.K) : (p.compressed ? b.take<bf16_t>(M * p.c.embed_rank) : nullptr);
     w.tok_table = b.take<float>((int64_t)N * D);
@@ -178,12 +190,13 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     w.x0 = (!p.student && p.image) ? b.take<float>(M * D) : nullptr;
     if (save) {
         w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
-        w.dbig = b.take<bf16_t>(M * F); w.dh = b.take<bf16_t>(M * D); w.dqkv = b.take<bf16_t>(M * 3 * D);
+        w.gb_f2 = b.take<bf16_t>(p.R * M * D); w.gb_pr = b.take<bf16_t>(p.R * M * D);
+        w.dbig = b.take<bf16_t>(p.R * M * F); w.dh = b.take<bf16_t>(M * D); w.dqkv = b.take<bf16_t>(p.R * M * 3 * D);
         w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
         w.tok_sum = b.take<float>((int64_t)N * D);
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {
-        w.G = nullptr; w.Gb = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr;
+        w.G = nullptr; w.Gb = nullptr; w.gb_f2 = w.gb_pr = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr;
     }
     w.bytes = b.off;
 }
@@ -405,7 +418,10 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     CK(gemm(w.dout, E, W + p.w_head_t, E, w.dh, D, B, D, E, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
     // every LayerNorm backward also emits the column sums of the updated residual gradient = the bias gradient of the
     // linear that wrote into that residual stream (fc2 of the previous execution / attn.proj of this one)
-    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, w.Gb, D, GR(f), GR(f + 1),
+    const int R = p.R;
+    bf16_t* gb_last = w.gb_f2 + (int64_t)(R - 1) * M * D;            // fc2 of the last execution reads slot R - 1
+    if (hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
+    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
                            GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
 
     // ---- blocks, last execution first --------------------------------------------------------------------------
@@ -416,29 +432,38 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         const SB sb = sblock(p, l); const SR sr = srepeat(p, l, r);
         const float *wl = nullptr, *ww = nullptr;
         if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
+        // this execution's slots; a block's wgrads run once, after its first execution's gradients are there (r == 0)
+        bf16_t* gb_f2 = w.gb_f2 + (int64_t)r * M * D;
+        bf16_t* gb_pr = w.gb_pr + (int64_t)r * M * D;
+        bf16_t* dbig = w.dbig + (int64_t)r * M * F;
+        bf16_t* dqkv = w.dqkv + (int64_t)r * M * 3 * D;
+        const int64_t MR = (int64_t)R * M;
+        const ExecSave& s0 = w.ex[ei - r];                               // execution r = 0 of this block: base of the [R][M, .] operands
         // gradient arriving directly at this execution's output (feature-MSE terms): G += d_rep[ei], refresh the bf16 copy
-        if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], w.Gb, M * D, GR(sb.f2b), D, st));
+        if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], gb_f2, M * D, GR(sb.f2b), D, st));
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        if (GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.Gb, D, s.u, F, GR(sb.f2w), F, M, D, F, wsplits(M, D, F), st));
-        CK(dclip_gemm_nt(w.Gb, D, W + bw.fc2_t, D, w.dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_MULAUX, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
+        CK(dclip_gemm_nt(gb_f2, D, W + bw.fc2_t, D, dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_MULAUX, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
                          GR(sb.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
-        if (GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s.h2, D, GR(sb.f1w), D, M, F, D, wsplits(M, F, D), st));
-        CK(gemm(w.dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, w.Gb, D, GR(sr.n2w), GR(sr.n2b),
+        if (r == 0 && GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(sb.f2w), F, MR, D, F, wsplits(MR, D, F), st));
+        if (r == 0 && GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(sb.f1w), D, MR, F, D, wsplits(MR, F, D), st));
+        CK(gemm(dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(sr.n2w), GR(sr.n2b),
                                GR(sb.prb), M, D, st));
         // attention: x_mid = x_in + proj(attn(LN1(x_in)))
-        if (GR(sb.prw)) CK(dclip_gemm_tn_acc(w.Gb, D, s.ctx, D, GR(sb.prw), D, M, D, D, wsplits(M, D, D), st));
+        if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), st));
         bf16_t* dctx = w.dh;
-        CK(gemm(w.Gb, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));                   // dR = dO V^T
-        CK(dclip_attn_tn(s.Rm, dctx, D, w.dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                       // dV = R^T dO
+        CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                         // dV = R^T dO
         CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr, wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
-        CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, w.dqkv, 3 * D, B, H, N, Np, hd, scale, st));                    // dQ = dS K
-        CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, w.dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                    // dK = dS^T Q
-        if (GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s.h1, D, GR(sb.qkvw), D, M, 3 * D, D, wsplits(M, 3 * D, D), st));
-        if (params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), M, 3 * D, st));
-        CK(gemm(w.dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, w.Gb, D, GR(sr.n1w), GR(sr.n1b),
+        CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, st));                      // dQ = dS K
+        CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                      // dK = dS^T Q
+        if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), st));
+        if (r == 0 && params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), MR, 3 * D, st));
+        CK(gemm(dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+        // the bf16 residual gradient leaving this execution is the fc2 operand of the previous one (slot of its repeat index)
+        bf16_t* gb_next = ei > 0 ? w.gb_f2 + (int64_t)((ei - 1) % R) * M * D : w.Gb;
+        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(sr.n1w), GR(sr.n1b),
                                ei > 0 ? GR(sblock(p, (ei - 1) / p.R).f2b) : nullptr, M, D, st));
     }
 
