@@ -994,7 +994,8 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     const bool fast = tn_mode != 0 && M % TC == 0 && P >= 8 && Q >= 8;
     // 256^2 pipeline for the large outputs: one workgroup per CU, every workgroup a long slice of the token axis
     static const int tn256_mode = [] { const char* e = getenv("DCLIP_TN256"); return e ? atoi(e) : 1; }();
-    if (tn256_mode != 0 && fast && P % 256 == 0 && Q % 256 == 0 && (P / 256) * (Q / 256) >= 16 && M >= 4096) {
+    static const int tn256_min_tiles = [] { const char* e = getenv("DCLIP_TN256_MIN_TILES"); return e ? atoi(e) : 16; }();
+    if (tn256_mode != 0 && fast && P % 256 == 0 && Q % 256 == 0 && (P / 256) * (Q / 256) >= tn256_min_tiles && M >= 4096) {
         GemmTN q = p;
         q.tiles_p = (int)(P / 256); q.tiles_q = (int)(Q / 256);
         const int tiles = q.tiles_p * q.tiles_q;
