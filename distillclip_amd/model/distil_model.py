@@ -55,7 +55,9 @@ class DistillModel(nn.Module):
         with torch.no_grad():
             teacher_outs = self.teacher(inputs, self.need_return_para)
         if self.hparams.norm:
-            raise NotImplementedError('norm=True (pre-normalised representations) is False in every shipped config')
+            # reference :86-88 (in place there; same values here, autograd-safe)
+            for o in (student_outs, teacher_outs):
+                o.last_representation = o.last_representation / o.last_representation.norm(dim=-1, keepdim=True)
         return student_outs, teacher_outs
 
     def training_step(self, inputs, batch_idx=0):

@@ -108,7 +108,10 @@ class DualDistillModel(nn.Module):
             teacher_outs = CLIPOutput(visual_output=outs[0], text_output=outs[1])
             student_outs = CLIPOutput(visual_output=outs[2], text_output=outs[3])
         if self.hparams.norm:
-            raise NotImplementedError('norm=True (pre-normalised representations) is False in every shipped config')
+            # reference :110-111 + norm_last_representation :278-284 (in place there; same values here, autograd-safe)
+            for outs in (student_outs, teacher_outs):
+                for o in (outs.visual_output, outs.text_output):
+                    o.last_representation = o.last_representation / o.last_representation.norm(dim=-1, keepdim=True)
         return student_outs, teacher_outs
 
     def training_step(self, inputs, batch_idx=0):

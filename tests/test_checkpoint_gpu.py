@@ -147,3 +147,35 @@ def test_frozen_teacher_reload_refreshes_weight_cache():
         m.teacher.load_state_dict(sd)
         _, t1 = m.forward(batch)
     assert torch.allclose(t1.visual_output.last_representation, 2.0 * r0, rtol=2e-2, atol=1e-4)
+
+
+def test_norm_true_pre_normalised_representations():
+    """DualDistillModel(norm=True) (reference dual_distill_model.py:110-111, :278-284): L2-normalised representations feed the
+    loss; loss and a gradient against the oracle on the same inputs"""
+    import oracle
+    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    seed = 13
+    sd_i, sd_t = T(synth.student_image_state(seed, **S_IMG)), T(synth.student_text_state(seed, **S_TXT))
+    s_img, s_txt = RepeatVisionTransformer(**S_IMG), RepeatTextTransformer(**S_TXT)
+    s_img.load_state_dict(sd_i)
+    s_txt.load_state_dict(sd_t)
+    tsd = _teacher_sd(7)
+    m = DualDistillModel(s_img, s_txt, dict(loss_name=['out_cos', 'out_kl'], temperature=2.0), warm_steps=1, total_steps=5,
+                         weight_decay=0.0, lr=1e-3, download_root='.', norm=True, teacher_state_dict=tsd).cuda()
+    image, text = _batch(0)
+    loss = m.training_step([image, text])
+    loss.backward()
+    for v in list(sd_i.values()) + list(sd_t.values()):
+        v.requires_grad_(True)
+    oi, ot = oracle.student_image_forward(sd_i, image.cpu(), 4), oracle.student_text_forward(sd_t, text.cpu(), 2)
+    with torch.no_grad():
+        ti = oracle.teacher_image_forward({k: v for k, v in tsd.items() if k.startswith('visual.')}, image.cpu())
+        tt = oracle.teacher_text_forward({k: v for k, v in tsd.items() if not k.startswith('visual.')}, text.cpu())
+    for o in (oi, ot, ti, tt):
+        o['last_representation'] = o['last_representation'] / o['last_representation'].norm(dim=-1, keepdim=True)
+    ref, _ = oracle.LossOracle(['out_cos', 'out_kl'], temperature=2.0)(oracle.clip_forward(oi, ot), oracle.clip_forward(ti, tt), 'all')
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-2 * abs(ref.item()) + 1e-6, (loss.item(), ref.item())
+    g, w = dict(m.student.image_encoder.named_parameters())['head.weight'].grad.cpu(), sd_i['head.weight'].grad
+    assert (g - w).norm().item() <= 8e-2 * w.norm().item()
