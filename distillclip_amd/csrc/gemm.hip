@@ -34,6 +34,7 @@ struct GemmNT {
     int row_group; const float* rowadd;
     float* colsum;                                  // += column sums of the epilogue output (bias gradient), may be null
     int tiles_m, tiles_n;
+    int preload;                                    // epilogue: fetch residual / aux rows of a slab ahead of its LDS staging
 };
 
 __device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }
@@ -252,9 +253,34 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int64_t
     __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(buf + (wave * 2 + 1) * SUB), 16, 0, 0);
 }
 
+// side operands of one output row segment, loaded ahead of use: residual and C may alias (in-place residual stream), so the
+// compiler cannot hoist these loads above the previous row's store by itself — left inside the row loop every row pays a
+// full HBM round trip in sequence
+struct EpiSide {
+    float4 r0, r1;      // residual
+    float4 a0, a1;      // rowadd
+    bf16x8 z;           // aux_in
+};
+
+template <int ACT>
+__device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int row, int col, EpiSide& sd) {
+    const int64_t o = (int64_t)row * p.ldc + col;
+    if (p.residual) {
+        const float* rp = p.residual + (int64_t)row * p.ldr + col;
+        sd.r0 = *(const float4*)rp; sd.r1 = *(const float4*)(rp + 4);
+    }
+    if (p.row_group > 0) {
+        const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
+        sd.a0 = *(const float4*)ra; sd.a1 = *(const float4*)(ra + 4);
+    }
+    if (ACT == 3 || ACT == 4) sd.z = *(const bf16x8*)(p.aux_in + o);
+}
+
 template <int ACT, bool OUT_F32>
 __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow, int row, int col, const float (&bias)[8],
-                                              float (&csum)[8]) {
+                                              float (&csum)[8], const EpiSide* pre) {
+    EpiSide sd;
+    if (pre) sd = *pre; else epilogue_load_side<ACT>(p, row, col, sd);
     float v[8];
     {
         const float4 c0 = *(const float4*)crow, c1 = *(const float4*)(crow + 4);
@@ -263,8 +289,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
     if (p.row_group > 0) {
-        const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
-        const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
+        const float4 a0 = sd.a0, a1 = sd.a1;
         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
     }
     const int64_t o = (int64_t)row * p.ldc + col;
@@ -283,12 +308,12 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
     }
     if (ACT == 3) {
-        const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+        const bf16x8 z = sd.z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
     }
     if (ACT == 4) {
-        const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
+        const bf16x8 z = sd.z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= bf2f(z[e]);
     }
@@ -303,8 +328,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
         if (p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
     }
     if (p.residual) {
-        const float* rp = p.residual + (int64_t)row * p.ldr + col;
-        const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+        const float4 r0 = sd.r0, r1 = sd.r1;
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
     if (OUT_F32) {
@@ -459,6 +483,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        // this slab's residual / aux rows start their HBM round trip before the accumulators go through LDS (only in the
+        // variants that have such operands: the others lose registers and time to it)
+        constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
+        EpiSide side[SIDE ? 4 : 1];
+        const bool pre = SIDE && p.preload;
+        if (pre && col < p.N) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int sl = (tid >> 5) + it * 16;
+                const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+                if (row < p.M) epilogue_load_side<ACT>(p, row, col, side[it]);
+            }
+        }
         __syncthreads();
         // slab row = wr * 32 + (0..31)  <->  tile row wr * 128 + q * 32 + (0..31)
 #pragma unroll
@@ -474,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             for (int it = 0; it < 4; ++it) {
                 const int sl = (tid >> 5) + it * 16;                     // slab row 0..63
                 const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
-                if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias, csum);
+                if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias, csum, pre ? &side[it] : nullptr);
             }
         }
     }
@@ -960,6 +997,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.residual = residual; p.ldr = ldr;
     p.row_group = (int)row_group; p.rowadd = rowadd; p.colsum = colsum_acc;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+    static const int epi_preload = [] { const char* e = getenv("DCLIP_EPI_PRELOAD"); return e ? atoi(e) : 1; }();
+    p.preload = epi_preload;
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
                   2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream);
