@@ -50,10 +50,25 @@ __device__ __forceinline__ uint8_t blend_px(int d, int v, float alpha, bool insi
     return (uint8_t)t;
 }
 
-__global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
+constexpr int AUG_THREADS = 1024;
+
+// dst = table[channel][src], pixel by pixel (three contiguous bytes per lane, no index division)
+__device__ __forceinline__ void apply_lut(const uint8_t* __restrict__ rs, uint8_t* __restrict__ wd, const uint8_t (*lut)[256],
+                                          int npix, int tid) {
+#pragma unroll 4
+    for (int p = tid; p < npix; p += AUG_THREADS) {
+        const uint8_t* q = rs + p * 3;
+        const uint8_t r = lut[0][q[0]], g = lut[1][q[1]], b = lut[2][q[2]];
+        wd[p * 3 + 0] = r; wd[p * 3 + 1] = g; wd[p * 3 + 2] = b;
+    }
+}
+      // one workgroup per image: the stages are latency-bound byte loops, so use every wave slot
+
+__global__ __launch_bounds__(AUG_THREADS) void augment_kernel(AugArgs a) {
     __shared__ unsigned hist[3][256];
     __shared__ uint8_t lut[3][256];
-    __shared__ unsigned long long red[4];
+    __shared__ float ntab[3][256];
+    __shared__ unsigned long long red[AUG_THREADS / 64];
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const int H = a.H, W = a.W, npix = H * W, nbytes = npix * 3;
@@ -64,8 +79,13 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     for (int s = 0; s < a.num_ops; ++s) {
         const dclip_aug_op op = a.ops[(int64_t)img * a.num_ops + s];
         if (op.op == OP_IDENTITY) continue;
+        // a stage reads one byte image and writes the other: restrict views let the loads of later iterations start before the
+        // stores of earlier ones (otherwise every iteration is a full load -> store round trip)
+        const uint8_t* __restrict__ rs = src;
+        uint8_t* __restrict__ wd = dst;
         if (op.op == OP_AFFINE || op.op == OP_SHIFT) {
-            for (int p = tid; p < npix; p += 256) {
+#pragma unroll 4
+            for (int p = tid; p < npix; p += AUG_THREADS) {
                 const int y = p / W, x = p - y * W;
                 int xin, yin;
                 if (op.op == OP_AFFINE) {
@@ -77,41 +97,47 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
                 }
                 uint8_t r = 0, g = 0, b = 0;
                 if (xin >= 0 && xin < W && yin >= 0 && yin < H) {
-                    const uint8_t* q = src + (yin * W + xin) * 3;
+                    const uint8_t* q = rs + (yin * W + xin) * 3;
                     r = q[0]; g = q[1]; b = q[2];
                 }
-                dst[p * 3 + 0] = r; dst[p * 3 + 1] = g; dst[p * 3 + 2] = b;
+                wd[p * 3 + 0] = r; wd[p * 3 + 1] = g; wd[p * 3 + 2] = b;
             }
         } else if (op.op == OP_BRIGHTNESS || op.op == OP_CONTRAST) {
             int deg = 0;
             if (op.op == OP_CONTRAST) {
                 unsigned long long sum = 0;
-                for (int p = tid; p < npix; p += 256) {
-                    const uint8_t* q = src + p * 3;
+                for (int p = tid; p < npix; p += AUG_THREADS) {
+                    const uint8_t* q = rs + p * 3;
                     sum += (unsigned)((q[0] * 19595 + q[1] * 38470 + q[2] * 7471 + 0x8000) >> 16);
                 }
                 for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
                 __syncthreads();
                 if ((tid & 63) == 0) red[tid >> 6] = sum;
                 __syncthreads();
-                sum = (red[0] + red[1]) + (red[2] + red[3]);
+                sum = 0;
+                for (int w = 0; w < AUG_THREADS / 64; ++w) sum += red[w];
                 deg = (int)((double)sum / (double)npix + 0.5);       // int(ImageStat.Stat(L).mean[0] + 0.5)
             }
+            // the blend against a constant is a function of the byte alone: 256-entry table, then the shared table pass
             const bool inside = op.f >= 0.f && op.f <= 1.f;
-            for (int i = tid; i < nbytes; i += 256) dst[i] = blend_px(deg, src[i], op.f, inside);
+            __syncthreads();
+            if (tid < 256) lut[0][tid] = lut[1][tid] = lut[2][tid] = blend_px(deg, tid, op.f, inside);
+            __syncthreads();
+            apply_lut(rs, wd, lut, npix, tid);
         } else if (op.op == OP_SHARPNESS) {
             const float k1 = 1.f / 13.f, k5 = 5.f / 13.f;               // (FLOAT32) kernel[i] / divisor, as Filter.c stores them
             const bool inside = op.f >= 0.f && op.f <= 1.f;
-            for (int i = tid; i < nbytes; i += 256) {
+#pragma unroll 4
+            for (int i = tid; i < nbytes; i += AUG_THREADS) {
                 const int p = i / 3, ch = i - p * 3;
                 const int y = p / W, x = p - y * W;
-                const int v = src[i];
+                const int v = rs[i];
                 int sm = v;                                              // one-pixel border: copied
                 if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
                     float ss = 0.5f;
 #pragma unroll
                     for (int dy = 1; dy >= -1; --dy) {
-                        const uint8_t* q = src + ((y + dy) * W + x) * 3 + ch;
+                        const uint8_t* q = rs + ((y + dy) * W + x) * 3 + ch;
                         const float kc = dy == 0 ? k5 : k1;
                         const float row = add_r(add_r(mul_r((float)q[-3], k1), mul_r((float)q[0], kc)),
                                                     mul_r((float)q[3], k1));
@@ -120,19 +146,25 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
                     const int t = (int)ss;
                     sm = t < 0 ? 0 : (t > 255 ? 255 : t);
                 }
-                dst[i] = blend_px(sm, v, op.f, inside);
+                wd[i] = blend_px(sm, v, op.f, inside);
             }
         } else if (op.op == OP_POSTERIZE) {
             const uint8_t mask = (uint8_t)op.c[0];
-            for (int i = tid; i < nbytes; i += 256) dst[i] = src[i] & mask;
+            __syncthreads();
+            if (tid < 256) lut[0][tid] = lut[1][tid] = lut[2][tid] = (uint8_t)tid & mask;
+            __syncthreads();
+            apply_lut(rs, wd, lut, npix, tid);
         } else {                                                         // OP_AUTOCONTRAST / OP_EQUALIZE
             __syncthreads();
-            for (int i = tid; i < 768; i += 256) (&hist[0][0])[i] = 0u;
+            for (int i = tid; i < 768; i += AUG_THREADS) (&hist[0][0])[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < nbytes; i += 256) atomicAdd(&hist[i % 3][src[i]], 1u);
+            for (int p = tid; p < npix; p += AUG_THREADS) {
+                const uint8_t* q = rs + p * 3;
+                atomicAdd(&hist[0][q[0]], 1u); atomicAdd(&hist[1][q[1]], 1u); atomicAdd(&hist[2][q[2]], 1u);
+            }
             __syncthreads();
             if (op.op == OP_AUTOCONTRAST) {
-                for (int ch = 0; ch < 3; ++ch) {
+                for (int ch = 0; ch < 3 && tid < 256; ++ch) {
                     int lo = 0, hi = 255;
                     while (lo < 256 && hist[ch][lo] == 0u) ++lo;
                     while (hi >= 0 && hist[ch][hi] == 0u) --hi;
@@ -149,37 +181,45 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
             } else {
                 if (tid < 3) {
                     const int ch = tid;
-                    long long total = 0, last = 0;
+                    unsigned total = 0, last = 0;
                     int nz = 0;
                     for (int i = 0; i < 256; ++i)
                         if (hist[ch][i]) { total += hist[ch][i]; last = hist[ch][i]; ++nz; }
-                    const long long step = nz <= 1 ? 0 : (total - last) / 255;
-                    long long n = step / 2;
+                    const unsigned step = nz <= 1 ? 0u : (total - last) / 255u;
+                    unsigned n = step / 2u;
                     for (int i = 0; i < 256; ++i) {
-                        long long v = step ? n / step : i;
-                        lut[ch][i] = (uint8_t)(v > 255 ? 255 : v);
+                        const unsigned v = step ? n / step : (unsigned)i;
+                        lut[ch][i] = (uint8_t)(v > 255u ? 255u : v);
                         n += hist[ch][i];
                     }
                 }
             }
             __syncthreads();
-            for (int i = tid; i < nbytes; i += 256) dst[i] = lut[i % 3][src[i]];
+            apply_lut(rs, wd, lut, npix, tid);
         }
         __threadfence_block();
         __syncthreads();                                                // the next stage reads what other lanes wrote
         src = dst;
         dst = dst == buf0 ? buf1 : buf0;
     }
-    // ToTensor + Normalize: float32(v) / 255, - mean, / std  (IEEE divisions, as torch's float32 kernels)
-    float* o = a.out + (int64_t)img * nbytes;
-    for (int i = tid; i < nbytes; i += 256) {
-        const int ch = i / npix, p = i - ch * npix;
-        const uint8_t v = src[p * 3 + ch];
-        o[i] = div_r(sub_r(div_r((float)v, 255.f), a.mean[ch]), a.stdv[ch]);
+    // ToTensor + Normalize: float32(v) / 255, - mean, / std (IEEE divisions, as torch's float32 kernels) — a function of
+    // (channel, byte): 768 table entries instead of two divisions per element
+    __syncthreads();
+    if (tid < 768) {
+        const int ch = tid >> 8, v = tid & 255;
+        ntab[ch][v] = div_r(sub_r(div_r((float)v, 255.f), a.mean[ch]), a.stdv[ch]);
+    }
+    __syncthreads();
+    float* __restrict__ o = a.out + (int64_t)img * nbytes;
+    const uint8_t* __restrict__ fin = src;
+#pragma unroll 4
+    for (int p = tid; p < npix; p += AUG_THREADS) {
+        const uint8_t* q = fin + p * 3;
+        o[p] = ntab[0][q[0]]; o[npix + p] = ntab[1][q[1]]; o[2 * npix + p] = ntab[2][q[2]];
     }
     if (a.aug_out) {
         uint8_t* ao = a.aug_out + (int64_t)img * nbytes;
-        for (int i = tid; i < nbytes; i += 256) ao[i] = src[i];
+        for (int i = tid; i < nbytes; i += AUG_THREADS) ao[i] = src[i];
     }
 }
 
@@ -204,7 +244,7 @@ extern "C" int dclip_augment_normalize(const uint8_t* images, int64_t B, int64_t
     a.in = images; a.ops = ops; a.num_ops = num_ops; a.B = (int)B; a.H = (int)H; a.W = (int)W;
     for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
     a.out = out; a.aug_out = aug_out; a.ws = (uint8_t*)workspace;
-    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)B), dim3(AUG_THREADS), 0, (hipStream_t)stream, a);
     return dclip_check_launch("dclip_augment_normalize");
 }
 
