@@ -363,7 +363,9 @@ __global__ void loss_total_kernel(LossArgs a) {
     }
     if (c.two_tower) {
         const float* s = a.scal;
-        o[9] = s[SC_POS] / B + (a.B > 1 ? s[SC_NEG] / (B * (B - 1.f)) : 0.f);
+        // B = 1 with cos_diff switched on: mean over no negatives = 0 / 0 = NaN, as the reference (clip_cos_diff.py:16-23);
+        // with the term off the raw value must stay finite (0 * NaN would poison the total)
+        o[9] = s[SC_POS] / B + ((a.B > 1 || a.c.w_cd != 0.f) ? s[SC_NEG] / (B * (B - 1.f)) : 0.f);
         o[10] = c.w_hl != 0.f ? 0.5f * ((s[SC_LSE0] - s[SC_DIAG]) / B + (s[SC_LSE1] - s[SC_DIAG]) / B) : 0.f;
         o[11] = 0.5f * (s[SC_KL0] + s[SC_KL1]) * c.tau * c.tau;
         o[12] = s[SC_MSE] / (B * B);
