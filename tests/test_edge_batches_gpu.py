@@ -93,3 +93,36 @@ def test_single_sample_cos_diff_is_nan_like_the_reference():
     loss = m.training_step([image.cuda(), text.cuda()])
     ref, _ = _oracle_loss(sd_i, sd_t, tsd, image, text, ['out_cos', 'cos_diff'])
     assert torch.isnan(ref) and torch.isnan(loss)
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_real_shapes_tiny_batch_forward(B):
+    """the shipped l_clip towers (ViT-B/32 teacher, 6x768/24h and 4x768/12h students) at B = 1 and 3: GEMM row counts of 50 / 77
+    (below one tile) through every tower, embeddings against the oracle"""
+    from distillclip_amd.model.component import (RepeatVisionTransformer, RepeatTextTransformer, ImageEncoder, TextEncoder)
+    seed = 17
+    s_img_cfg = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                     mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    sd_si, sd_st = T(synth.student_image_state(seed, **s_img_cfg)), T(synth.student_text_state(seed, **s_txt_cfg))
+    sd_ti, sd_tt = T(synth.teacher_image_state(seed)), T(synth.teacher_text_state(seed))
+    s_img, s_txt = RepeatVisionTransformer(**s_img_cfg), RepeatTextTransformer(**s_txt_cfg)
+    s_img.load_state_dict(sd_si)
+    s_txt.load_state_dict(sd_st)
+    t_img = ImageEncoder(False, dict(input_resolution=224, patch_size=32, width=768, layers=12, heads=12, output_dim=512))
+    t_img.load_state_dict(sd_ti)
+    t_txt = TextEncoder(512, 12, 8, 77, None, 49408, 512, is_student=False)
+    t_txt.load_state_dict(sd_tt)
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    text = torch.from_numpy(synth.captions(seed, B))
+    with torch.no_grad():
+        got = {'s_img': s_img.cuda()(image.cuda()).last_representation, 's_txt': s_txt.cuda()(text.cuda()).last_representation,
+               't_img': t_img.cuda()(image.cuda()).last_representation, 't_txt': t_txt.cuda()(text.cuda()).last_representation}
+        want = {'s_img': oracle.student_image_forward(sd_si, image, 24)['last_representation'],
+                's_txt': oracle.student_text_forward(sd_st, text, 12)['last_representation'],
+                't_img': oracle.teacher_image_forward(sd_ti, image)['last_representation'],
+                't_txt': oracle.teacher_text_forward(sd_tt, text)['last_representation']}
+    for k in got:
+        g, w = got[k].float().cpu(), want[k]
+        rel = ((g - w).norm() / w.norm()).item()
+        assert rel < 2e-2, (B, k, rel)
