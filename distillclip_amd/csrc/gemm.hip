@@ -957,15 +957,49 @@ bool use_256(const GemmNT& p) {
     return e256 * 1.2 > e128;
 }
 
+// rows [0, rows) of the problem stay, the rest is cut off: every row-indexed operand advances
+inline GemmNT tail_rows(GemmNT p, int rows, bool out_f32) {
+    p.A += (int64_t)rows * p.lda;
+    p.C = (char*)p.C + (int64_t)rows * p.ldc * (out_f32 ? 4 : 2);
+    if (p.residual) p.residual += (int64_t)rows * p.ldr;
+    if (p.aux_in) p.aux_in += (int64_t)rows * p.ldc;
+    if (p.aux_out) p.aux_out += (int64_t)rows * p.ldc;
+    p.M -= rows;
+    return p;
+}
+
 template <int ACT>
 int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
     if (use_256(p)) {
-        p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+        int tm = (p.M + 255) / 256;
+        const int tn = (p.N + 255) / 256;
+        // Wave quantisation: T tiles on 256 CUs (one 256^2 workgroup each) take ceil(T / 256) rounds.  When the last round would
+        // be mostly empty (300 tiles for every N = 768 GEMM of the image towers: 44 tiles in round 2), the row tiles that fill
+        // whole rounds go to the 256^2 kernel and the remaining rows to the 128^2 kernel (2-3 workgroups per CU), whose short
+        // tiles turn the second round into a fraction of one.
+        // Opt-in (DCLIP_GEMM_SPLITM=1): +2 % step throughput when the towers share one stream, -0.4 % with the default four
+        // streams, where the other towers' kernels already fill the tail round.
+        static const int split_mode = [] { const char* e = getenv("DCLIP_GEMM_SPLITM"); return e ? atoi(e) : 0; }();
+        const int T = tm * tn, R = T / 256, tail = T - 256 * R;
+        GemmNT rest = p;
+        bool has_rest = false;
+        if (split_mode && p.row_group == 0 && R >= 1 && tail > 0 && tail < 160) {
+            const int tm1 = (256 * R) / tn;
+            if (tm1 >= 1 && tm1 < tm) {
+                rest = tail_rows(p, tm1 * 256, out_f32);
+                has_rest = true;
+                p.M = tm1 * 256;
+                tm = tm1;
+            }
+        }
+        p.tiles_m = tm; p.tiles_n = tn;
         const int grid256 = p.tiles_m * p.tiles_n;
         const size_t lds256 = 8 * HT;
         if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true>), dim3(grid256), dim3(512), lds256, st, p);
         else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false>), dim3(grid256), dim3(512), lds256, st, p);
-        return dclip_check_launch("dclip_gemm_nt");
+        if (!has_rest) return dclip_check_launch("dclip_gemm_nt");
+        p = rest;
+        p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
     }
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NT_LDS;

@@ -183,3 +183,30 @@ def test_gelu_epilogue_accuracy_over_range():
     assert (saved.float() - zf.grad).abs().max().item() < 5e-3                              # one bf16 rounding of a value in [-0.13, 1.13]
     d2 = ops.gemm_nt(a, ones, act='mulaux', aux_in=saved, out_dtype=torch.float32)
     assert torch.equal(d2, saved.float())
+
+
+@pytest.mark.parametrize('M,N,K', [(22272, 768, 128), (19800, 512, 64)])
+def test_gemm_nt_row_split_between_tile_sizes(M, N, K):
+    """T = 261 / 156 x 2 = 312 tiles of 256^2: with DCLIP_GEMM_SPLITM=1 (opt-in, read once per process) the launcher gives the rows of
+    the full rounds to the 256^2 kernel and the tail rows to the 128^2 kernel; every row-indexed operand (residual, aux_in /
+    aux_out, column sums) must follow the cut.  Without the knob the same assertions cover the single-kernel path."""
+    from distillclip_amd import ops
+    a, b = _rand((M, K), 31), _rand((N, K), 32, 0.2)
+    bias = torch.randn(N, device='cuda')
+    ref = a.float() @ b.float().t()
+    _close(ops.gemm_nt(a, b, out_dtype=torch.float32), ref, 1e-5 * K ** 0.5 + 1e-5)
+    res = torch.randn(M, N, device='cuda')
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    cs = torch.zeros(N, device='cuda')
+    out = ops.gemm_nt(a, b, bias=bias, act='gelu_save', aux_out=aux, residual=res, out_dtype=torch.float32, colsum=cs)
+    z = (ref + bias).requires_grad_(True)
+    y = torch.nn.functional.gelu(z)
+    y.sum().backward()
+    _close(out, y.detach() + res, 1e-4)
+    _close(aux, z.grad, 6e-3)
+    _close(cs, out.sum(0), 2e-4)
+    d = ops.gemm_nt(a, b, act='mulaux', aux_in=aux, out_dtype=torch.bfloat16)
+    _close(d, ref * aux.float(), 6e-3)
+    x = res.clone()
+    ops.gemm_nt(a, b, bias=bias, residual=x, out=x)                       # in-place residual stream
+    _close(x, ref + bias + res, 1e-4)
