@@ -63,7 +63,7 @@ class _Lib:
 
     def __getattr__(self, name):
         fn = getattr(self._dll, name)
-        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name == 'dclip_version':
+        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name == 'dclip_version' or name.endswith('_supported'):
             return fn
 
         def call(*args):

@@ -203,6 +203,15 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
 
 inline const float* PF(const void* const* params, int i) { return (const float*)params[i]; }
 
+// DCLIP_FUSED_ATTN=1 (opt-in): head-mixing students of the shipped shapes run the attention forward as ONE kernel, which saves the
+// pre-mix scores as bf16 (forward and backward must agree on that format, hence one predicate for both).  Off by default: the
+// first version of that kernel moves 43 % fewer bytes but, at one 153 KiB workgroup per CU, is latency-bound (318 / 818 us
+// against 170 / 230 us for the three bandwidth-bound kernels at B = 512); see DESIGN.md section 7.
+inline bool fused_student_attn(const Plan& p, int64_t N) {
+    static const int mode = [] { const char* e = getenv("DCLIP_FUSED_ATTN"); return e ? atoi(e) : 0; }();
+    return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_student_fwd_supported(p.H, N, p.hd) != 0;
+}
+
 // split count of the wgrad contraction: minimise  rounds(tiles*s / 512 resident workgroups) * work per workgroup
 //                                                   + atomic traffic (s * P*Q*4 bytes at ~1.3 TB/s, half hidden)
 inline int wsplits(int64_t M, int64_t P, int64_t Q) {
@@ -366,9 +375,13 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
             // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
             CK(dclip_attn_fused_fwd(s.qkv, 3 * D, s.ctx, D, B, H, N, hd, scale, p.c.causal, st));
         } else {
-            CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
-            CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
-            CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+            if (wl && fused_student_attn(p, N)) {
+                CK(dclip_attn_student_fwd(s.qkv, 3 * D, wl, ww, s.S, s.P, s.Rm, s.ctx, D, B, H, N, Np, hd, scale, st));
+            } else {
+                CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
+                CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
+                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+            }
         }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
         CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
@@ -455,7 +468,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));                   // dR = dO V^T
         CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                         // dV = R^T dO
-        CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr, wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
+        CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
+                                  wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
         CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, st));                      // dQ = dS K
         CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                      // dK = dS^T Q
         if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), st));

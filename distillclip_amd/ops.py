@@ -108,7 +108,8 @@ def attn_softmax_fwd(s, wl=None, ww=None, causal=False, save_p=False):
 def attn_softmax_bwd(dr, p, s, wl=None, ww=None, dwl=None, dww=None):
     B, H, N, Np = dr.shape
     ds = torch.empty_like(dr)
-    lib().dclip_attn_softmax_bwd(_p(dr), _p(p), _p(s), _p(wl), _p(ww), _p(ds), _p(dwl), _p(dww), B, H, N, Np, _stream())
+    lib().dclip_attn_softmax_bwd(_p(dr), _p(p), _p(s), 1 if (s is not None and s.dtype == torch.bfloat16) else 0, _p(wl), _p(ww), _p(ds),
+                                 _p(dwl), _p(dww), B, H, N, Np, _stream())
     return ds
 
 
@@ -163,3 +164,19 @@ def feature_mse(s, t, coef=1.0):
     ds = torch.zeros_like(s)
     lib().dclip_feature_mse(_p(s), _p(t), s.numel(), float(coef), _p(val), _p(ds), _stream())
     return val[0], ds
+
+
+def attn_student_fwd(qkv, B, N, H, hd, wl, ww, scale, save=True):
+    """fused student attention forward: -> (ctx [B*N, H*hd] bf16, S, P, R [B,H,N,Np] bf16); see include/dclip.h"""
+    _chk(qkv, wl, ww)
+    Np = (N + 7) // 8 * 8
+    D = H * hd
+    assert qkv.dtype == torch.bfloat16 and qkv.shape == (B * N, 3 * D) and qkv.stride(1) == 1
+    if not lib().dclip_attn_student_fwd_supported(H, N, hd):
+        raise ValueError(f'attn_student_fwd: no fused instantiation for H={H} N={N} hd={hd}')
+    mk = lambda: torch.zeros((B, H, N, Np), dtype=torch.bfloat16, device=qkv.device)
+    S, P, R = (mk() if save else None), (mk() if save else None), mk()
+    ctx = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    lib().dclip_attn_student_fwd(_p(qkv), qkv.stride(0), _p(wl), _p(ww), _p(S), _p(P), _p(R), _p(ctx), D, B, H, N, Np, hd, float(scale),
+                                 _stream())
+    return ctx, S, P, R

@@ -108,8 +108,19 @@ int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, i
                          float scale, int causal, void* stream);
 int dclip_attn_softmax_fwd(const float* S, const float* Wl, const float* Ww, void* P, void* R, int64_t B, int64_t H,
                            int64_t N, int64_t Np, int causal, void* stream);
-int dclip_attn_softmax_bwd(const void* dR, const void* P, const float* S, const float* Wl, const float* Ww, void* dS,
-                           float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np, void* stream);
+int dclip_attn_softmax_bwd(const void* dR, const void* P, const void* S, int scores_bf16, const float* Wl, const float* Ww,
+                           void* dS, float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np, void* stream);
+/*
+ * Fused student attention forward (reference weight_share_model.py:88-140 MiniAttention.forward with conv_l / conv_w):
+ *   ctx[(b,i), h*hd + :] = conv_w(softmax(conv_l(scale * q k^T))) v  from the packed qkv rows [B*N, 3*H*hd] (ld elements),
+ *   and the tensors the backward needs: S (pre-mix scores, bf16; nullable), P (probabilities, bf16; nullable), R (mixed
+ *   probabilities, bf16), each [B,H,N,Np].  The scores are written once and never read back in the forward.
+ *   dclip_attn_student_fwd_supported(H, N, hd) tells whether a fused instantiation exists for the shape (the students of the
+ *   shipped configs); other shapes use dclip_attn_nt + dclip_attn_softmax_fwd + dclip_attn_nn.
+ */
+int dclip_attn_student_fwd_supported(int64_t H, int64_t N, int64_t hd);
+int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* S, void* P, void* R, void* ctx,
+                           int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Embedding-side helpers (HBM-bound).

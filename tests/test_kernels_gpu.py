@@ -165,3 +165,50 @@ def test_embed_scatter_add_with_hot_ids():
     ref = torch.ones(V, D, device='cuda').index_add_(0, ids, dx)
     _close(tab, ref, 1e-5)
     assert ref[0].abs().sum() > 0 and ref[V - 1].abs().sum() > 0
+
+
+@pytest.mark.parametrize('B,N,H,hd', [(3, 50, 24, 32), (2, 77, 12, 64), (1, 17, 24, 32), (2, 65, 12, 64), (5, 64, 24, 32), (1, 128, 12, 64)])
+def test_fused_student_attention_forward(B, N, H, hd):
+    """dclip_attn_student_fwd (scores -> conv_l -> softmax -> conv_w -> values in one kernel; reference
+    weight_share_model.py:88-140) against the three-kernel path and a plain fp32 graph, and its saved tensors through the
+    backward (bf16 scores)"""
+    from distillclip_amd import ops
+    D = H * hd
+    Np = (N + 7) // 8 * 8
+    qkv = _randn((B * N, 3 * D), 41, 0.7, torch.bfloat16)
+    wl = torch.eye(H, device='cuda') + _randn((H, H), 42, 0.15)
+    ww = torch.eye(H, device='cuda') + _randn((H, H), 43, 0.15)
+    scale = hd ** -0.5
+    ctx, S, P, R = ops.attn_student_fwd(qkv, B, N, H, hd, wl, ww, scale)
+    # three-kernel path on the same inputs
+    s3 = ops.attn_nt(qkv, 3 * D, qkv[:, D:], 3 * D, B, H, N, hd, alpha=scale)
+    p3, r3 = ops.attn_softmax_fwd(s3, wl, ww, save_p=True)
+    c3 = torch.zeros(B * N, D, dtype=torch.bfloat16, device='cuda')
+    ops.attn_nn(r3, qkv[:, 2 * D:], 3 * D, c3, D, hd)
+    _close(S[..., :N], s3[..., :N], 6e-3, 'S')
+    _close(P[..., :N], p3[..., :N], 8e-3, 'P')          # one bf16 ulp: the H = 12 three-kernel path mixes on the VALU in f32
+    _close(R[..., :N], r3[..., :N], 8e-3, 'R')
+    _close(ctx, c3, 6e-3, 'ctx vs three kernels')
+    assert torch.count_nonzero(P[..., N:]) == 0 and torch.count_nonzero(R[..., N:]) == 0 and torch.count_nonzero(S[..., N:]) == 0
+    # fp32 graph
+    q, k, v = (_heads(qkv[:, i * D:(i + 1) * D], B, N, H, hd) for i in range(3))
+    a = torch.einsum('gh,bhij->bgij', wl, (q @ k.transpose(-1, -2)) * scale)
+    r = torch.einsum('gh,bhij->bgij', ww, a.softmax(-1))
+    ref = (r @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    _close(ctx, ref, 1e-2, 'ctx vs fp32')
+    # backward consumes the bf16 scores
+    dr = torch.zeros(B, H, N, Np, dtype=torch.bfloat16, device='cuda')
+    dr[..., :N] = _randn((B, H, N, N), 44, 1.0, torch.bfloat16)
+    dwl_a, dww_a, dwl_b, dww_b = (torch.zeros(H, H, device='cuda') for _ in range(4))
+    ds_a = ops.attn_softmax_bwd(dr, P, S, wl, ww, dwl_a, dww_a)
+    ds_b = ops.attn_softmax_bwd(dr, p3, s3, wl, ww, dwl_b, dww_b)
+    _close(ds_a[..., :N], ds_b[..., :N], 1.5e-2, 'dS')      # P differs by single bf16 ulps between the two forward paths
+    _close(dwl_a, dwl_b, 3e-2, 'dWl')
+    _close(dww_a, dww_b, 3e-2, 'dWw')
+
+
+def test_fused_student_attention_support_matrix():
+    from distillclip_amd._lib import lib
+    assert lib().dclip_attn_student_fwd_supported(24, 50, 32) and lib().dclip_attn_student_fwd_supported(12, 77, 64)
+    assert not lib().dclip_attn_student_fwd_supported(12, 50, 64) and not lib().dclip_attn_student_fwd_supported(8, 77, 64)
+    assert not lib().dclip_attn_student_fwd_supported(24, 65, 32) and not lib().dclip_attn_student_fwd_supported(12, 129, 64)
