@@ -34,8 +34,9 @@ struct LossArgs {
     float* ds[2];
     float* nrm[4];                            // normalised s_img, s_txt, t_img, t_txt  [B,E]
     float* inv[2];                            // 1 / |s|
-    float* stats;                             // [6][B]: r1S rtS rtT c1S ctS ctT
-    float* dsh[2];                            // d loss / d normalised student embedding [B,E]
+    float* stats;                             // [zs][6][B]: r1S rtS rtT c1S ctS ctT, one partial per column slice
+    int zs;                                   // column slices of the stripe kernels (blockIdx.z): fills the chip at B = 512
+    float* dsh[2];                            // d loss / d normalised student embedding [zs][B,E] (partials per slice)
     float* scal;                              // [NSC] atomically accumulated
     float* out;                               // [16] user-visible scalars
     int B, E;
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
     float r1[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, rt[4] = {0, 0, 0, 0};
     float pos = 0.f, neg = 0.f, mse = 0.f, diag = 0.f;
     const int ntile = (B + 15) / 16;
-    for (int jt = wave; jt < ntile; jt += 4) {
+    const int z = blockIdx.z, t0 = (int)((int64_t)ntile * z / a.zs), t1 = (int)((int64_t)ntile * (z + 1) / a.zs);   // this slice's column tiles
+    for (int jt = t0 + wave; jt < t1; jt += 4) {
         const int j0 = jt * 16;
         const int jb = min(j0 + (lane & 15), B - 1) - (lane & 15);
         const f32x4 S = logits_tile(sa + (int64_t)ia * E, sb + (int64_t)jb * E, E, lane);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
         const int r = threadIdx.x % 16, k = threadIdx.x / 16;
         if (i0 + r < B) {
             const float v = (red[0][r][k] + red[1][r][k]) + (red[2][r][k] + red[3][r][k]);
-            a.stats[(int64_t)(dir * 3 + k) * B + i0 + r] = v;
+            a.stats[((int64_t)z * 6 + dir * 3 + k) * B + i0 + r] = v;
         }
     }
 }
@@ -241,26 +243,33 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
     // row statistics of this direction, column statistics = row statistics of the other direction
     const float* rst = a.stats + (int64_t)dir * 3 * B;
     const float* cst = a.stats + (int64_t)(1 - dir) * 3 * B;
+    // the row / column sums arrive as one partial per column slice of pass A: added in slice order (deterministic)
+    auto stat = [&](const float* base, int idx) {
+        float v = 0.f;
+        for (int zz = 0; zz < a.zs; ++zz) v += base[(int64_t)zz * 6 * B + idx];
+        return v;
+    };
     const int ia = min(i0 + (lane & 15), B - 1) - (lane & 15);
     float rr1[4], rrs[4], rrt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = min(i0 + (lane >> 4) * 4 + q, B - 1);
-        rr1[q] = rst[row]; rrs[q] = rst[B + row]; rrt[q] = rst[2 * B + row];
+        rr1[q] = stat(rst, row); rrs[q] = stat(rst, B + row); rrt[q] = stat(rst, 2 * B + row);
     }
+    const int z = blockIdx.z, t0 = (int)((int64_t)ntile * z / a.zs), t1 = (int)((int64_t)ntile * (z + 1) / a.zs);
     const float k_cd_pos = a.c.w_cd / B, k_cd_neg = B > 1 ? a.c.w_cd / ((float)B * (B - 1)) : 0.f;
     const float k_mse = a.c.w_mse * 2.f / ((float)B * B);
     const float k_hl = a.c.w_hl * 0.5f / B;
     const float k_sl = a.c.w_sl * 0.5f * tau;
     float klacc = 0.f;
-    for (int jt = wave; jt < ntile; jt += 4) {
+    for (int jt = t0 + wave; jt < t1; jt += 4) {
         const int j0 = jt * 16;
         const int jb = min(j0 + (lane & 15), B - 1) - (lane & 15);
         const f32x4 S = logits_tile(sa + (int64_t)ia * E, sb + (int64_t)jb * E, E, lane);
         const f32x4 T = logits_tile(ta + (int64_t)ia * E, tb + (int64_t)jb * E, E, lane);
         const int col = j0 + (lane & 15);
         const int cc = min(col, B - 1);
-        const float c1 = cst[cc], cs = cst[B + cc], ct = cst[2 * B + cc];
+        const float c1 = stat(cst, cc), cs = stat(cst, B + cc), ct = stat(cst, 2 * B + cc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rl = (lane >> 4) * 4 + q, row = i0 + rl;
@@ -290,17 +299,18 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         klacc = wave_sum(klacc);
         if (lane == 0) unsafeAtomicAdd(a.scal + (dir ? SC_KL1 : SC_KL0), klacc);
     }
-    if (a.c.w_hl != 0.f && wave == 0 && lane < 16 && i0 + lane < B)
-        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(rst[i0 + lane]) + 1.f);
+    if (a.c.w_hl != 0.f && z == 0 && wave == 0 && lane < 16 && i0 + lane < B)
+        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(stat(rst, i0 + lane)) + 1.f);
     __syncthreads();
     // gradient rows: G[16, E] = dS_stripe[16, B] @ Y[B, E],  Y = normalised student embedding of the other modality
+    // (this slice's columns only: the slices' partial rows are added in loss_finalize_kernel)
     const float* Y = sb;
-    float* G = a.dsh[dir];
+    float* G = a.dsh[dir] + (int64_t)z * B * E;
     const float* arow = dsl + (lane & 15) * ldl + (lane >> 4) * 4;
     for (int e0 = wave * 16; e0 < E; e0 += 64) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* yb = Y + e0 + (lane & 15);
-        for (int o = 0; o < ntile * 16; o += 16) {
+        for (int o = t0 * 16; o < t1 * 16; o += 16) {
             const float4 av = *(const float4*)(arow + o);
             const int k0 = o + (lane >> 4) * 4;
             // rows beyond B carry zero weights in dsl; clamp the address only
@@ -326,10 +336,17 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
     if (b >= a.B) return;
     for (int tow = 0; tow < 2; ++tow) {
         const float* xh = a.nrm[tow] + (int64_t)b * a.E;
-        const float* g = a.dsh[tow] + (int64_t)b * a.E;
+        float* g = a.dsh[tow] + (int64_t)b * a.E;
+        const int64_t zstride = (int64_t)a.B * a.E;
         float dot = 0.f;
         for (int c = lane * 4; c < a.E; c += 256) {
-            const float4 x = *(const float4*)(xh + c), y = *(const float4*)(g + c);
+            float4 y = *(const float4*)(g + c);
+            for (int zz = 1; zz < a.zs; ++zz) {                     // slice order: deterministic
+                const float4 p = *(const float4*)(g + zz * zstride + c);
+                y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
+            }
+            *(float4*)(g + c) = y;                                  // slice 0 now holds the complete row
+            const float4 x = *(const float4*)(xh + c);
             dot += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
         }
         dot = wave_sum(dot);
@@ -377,11 +394,21 @@ __global__ void loss_total_kernel(LossArgs a) {
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// column slices of the stripe kernels: 2 * ceil(B / 16) stripes alone fill 64 of the 256 CUs at B = 512, and the loss sits
+// alone on the critical path between the forward and the backward
+inline int loss_slices(int64_t B) {
+    const int ntile = (int)((B + 15) / 16);
+    int zs = 256 / (2 * ntile);
+    zs = zs < 1 ? 1 : (zs > 8 ? 8 : zs);
+    return zs > ntile ? ntile : zs;
+}
+
 }  // namespace
 
 extern "C" size_t dclip_distill_loss_workspace(int64_t B, int64_t E) {
     const size_t be = align_up((size_t)B * E * sizeof(float));
-    return 6 * be + align_up((size_t)2 * B * 4) + align_up((size_t)6 * B * 4) + align_up(NSC * 4);
+    const size_t zs = (size_t)loss_slices(B);
+    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up(NSC * 4);
 }
 
 extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B,
@@ -404,9 +431,10 @@ extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const 
     char* w = (char*)workspace;
     const size_t be = align_up((size_t)B * E * sizeof(float));
     for (int i = 0; i < 4; ++i) { a.nrm[i] = (float*)w; w += be; }
-    for (int i = 0; i < 2; ++i) { a.dsh[i] = (float*)w; w += be; }
+    a.zs = loss_slices(B);
+    for (int i = 0; i < 2; ++i) { a.dsh[i] = (float*)w; w += (size_t)a.zs * be; }
     a.inv[0] = (float*)w; a.inv[1] = a.inv[0] + B; w += align_up((size_t)2 * B * 4);
-    a.stats = (float*)w; w += align_up((size_t)6 * B * 4);
+    a.stats = (float*)w; w += align_up((size_t)a.zs * 6 * B * 4);
     a.scal = (float*)w;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic HBM bytes: read 4*B*E*4 + write 2*B*E*4 ; the [B,B] logits contribute none
@@ -425,7 +453,7 @@ extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const 
     }
     const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
     if (cross) {
-        const dim3 grid((unsigned)((B + 15) / 16), 2);
+        const dim3 grid((unsigned)((B + 15) / 16), 2, (unsigned)a.zs);
         hipLaunchKernelGGL(loss_stripe_a_kernel, grid, dim3(256), 0, st, a);
         const size_t lds = (size_t)16 * (((B + 15) / 16) * 16 + 4) * sizeof(float);
         DCLIP_REQUIRE(lds <= 160 * 1024, "dclip_distill_loss: stripe does not fit LDS");
