@@ -1091,7 +1091,10 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
 
 extern "C" int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N, void* stream) {
     DCLIP_REQUIRE(X && db && M > 0 && N > 0, "dclip_colsum_acc: bad argument");
-    int rows_per_block = 512;
+    // enough row slices to put >= ~512 workgroups on the chip (a [512, 512] head gradient used to run on 2 workgroups)
+    const int colblocks = (int)((N + 255) / 256);
+    int rows_per_block = (int)((M * colblocks + 511) / 512);
+    rows_per_block = rows_per_block < 16 ? 16 : (rows_per_block > 512 ? 512 : (rows_per_block + 3) & ~3);
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rows_per_block - 1) / rows_per_block));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ld, db, (int)M, (int)N,
                        rows_per_block);
