@@ -77,18 +77,24 @@ __global__ void token_table_kernel(const float* __restrict__ pos, const float* _
 }
 
 // tok_sum[n] = sum_b G[b,n,:]  ->  dpos += tok_sum ; dcls += tok_sum[0] ; dbias += sum_{n>=cls} tok_sum[n]
+// grid (ceil(D / 256), ntok): one (token, column) per thread; the row-0 workgroups also reduce the bias column sums (loads only,
+// so they pipeline) — the previous one-thread-per-column loop was a chain of 50-77 dependent read-modify-writes at the very end
+// of a tower's backward
 __global__ void token_table_bwd_kernel(const float* __restrict__ ts, float* __restrict__ dpos, float* __restrict__ dcls,
                                        float* __restrict__ dbias, int ntok, int D, int has_cls) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
-    float sb = 0.f;
-    for (int n = 0; n < ntok; ++n) {
-        const float v = ts[n * D + c];
-        if (dpos) dpos[n * D + c] += v;
-        if (n >= has_cls) sb += v;
+    const int n = blockIdx.y;
+    const float v = ts[n * D + c];
+    if (dpos) dpos[n * D + c] += v;
+    if (n == 0) {
+        if (dcls && has_cls) dcls[c] += v;
+        if (dbias) {
+            float sb = 0.f;
+            for (int m = has_cls; m < ntok; ++m) sb += ts[m * D + c];
+            dbias[c] += sb;
+        }
     }
-    if (dcls && has_cls) dcls[c] += ts[c];
-    if (dbias) dbias[c] += sb;
 }
 
 // out[n,:] += sum_b G[b,n,:]   grid (ceil(D/256), N, bsplit)
@@ -262,7 +268,7 @@ extern "C" int dclip_token_table(const float* pos, const float* cls, const float
 extern "C" int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D,
                                      int has_cls, void* stream) {
     DCLIP_REQUIRE(tok_sum && ntok > 0 && D > 0, "dclip_token_table_bwd: bad argument");
-    hipLaunchKernelGGL(token_table_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok_sum,
+    hipLaunchKernelGGL(token_table_bwd_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)ntok), dim3(256), 0, (hipStream_t)stream, tok_sum,
                        dpos, dcls, dbias, (int)ntok, (int)D, has_cls);
     return dclip_check_launch("dclip_token_table_bwd");
 }
