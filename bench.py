@@ -21,6 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# one hardware queue per tower stream (+ main + RCCL): read at HIP initialisation, see distillclip_amd/__init__.py
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
