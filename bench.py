@@ -138,11 +138,13 @@ def main():
     tt_tokens = int((caps != 0).sum(1).max()) if args.teacher_text_prefix else 77
     model.set_text_length_hint(tt_tokens if args.teacher_text_prefix else None)
 
+    FUSED_ZERO = os.environ.get('DCLIP_BENCH_FUSED_ZERO', '1') != '0'
+
     def step():
         loss = model.training_step([image, text])
         opt.zero_grad()
         model.backward_and_sync(loss)
-        opt.step()
+        opt.step(zero_grad=FUSED_ZERO)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
         return loss
 
     def barrier():

@@ -193,9 +193,9 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds, c
 }
 
 // torch.optim.AdamW semantics (decoupled weight decay; bias-corrected), reference distil_model.py:160-162
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i];
         float pi = p[i] * (1.f - lr * wd);
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         pi -= (lr / bc1) * (mi / denom);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;                // the gradient is consumed: leave the accumulator clean for the next backward
     }
 }
 
@@ -321,13 +322,13 @@ extern "C" int dclip_gather_rows(const float* src, int64_t ld, const int32_t* id
     return dclip_check_launch("dclip_gather_rows");
 }
 
-extern "C" int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, int64_t step, void* stream) {
+extern "C" int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int64_t step, int zero_grad, void* stream) {
     DCLIP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dclip_adamw: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2);
+                       weight_decay, bc1, bc2, zero_grad);
     return dclip_check_launch("dclip_adamw");
 }
 

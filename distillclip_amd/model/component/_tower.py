@@ -43,6 +43,7 @@ class HipTower:
         self._ws_key = None
         self._saved_batch = None
         self.bwd_done = None
+        self._grad_clean = False                  # True after an optimizer step that cleared the gradients it consumed
         # load_state_dict copies into the flat buffer in place: frozen towers must re-cast their bf16 weight cache afterwards
         module.register_load_state_dict_post_hook(lambda m, incompatible: setattr(self, 'wcache_dirty', True))
 
@@ -162,6 +163,7 @@ class HipTower:
             raise RuntimeError('backward without a matching training-mode forward (activations are kept in the workspace '
                                'of the most recent forward)')
         self.attach_grads()
+        self._grad_clean = False                  # the kernels below accumulate into the flat gradient buffer
         ps = self._params()
         gs = [None if (p is None or not p.requires_grad) else p.grad for p in ps]
         if d_out is None:

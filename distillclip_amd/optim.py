@@ -42,11 +42,18 @@ class FusedAdamW:
 
     def zero_grad(self, set_to_none=False):
         for tw in self.towers:
-            if tw.flat_grad is not None:
+            if tw.flat_grad is not None and not getattr(tw, '_grad_clean', False):
                 tw.flat_grad.zero_()
 
+    def _ranges_cover_everything(self, tw):
+        r = self._ranges(tw)
+        return len(r) == 1 and r[0][0] == 0 and r[0][1] >= tw.flat.numel()
+
     @torch.no_grad()
-    def step(self):
+    def step(self, zero_grad=False):
+        """zero_grad=True: the kernel clears each gradient element once it has consumed it (saves the separate 306 MB fill that
+        otherwise runs alone on the main stream); the next zero_grad() is then free.  Frozen ranges are never written by the
+        backward, so a fully trainable tower stays clean until its next backward."""
         self.step_count += 1
         st = torch.cuda.current_stream().cuda_stream
         for tw in self.towers:
@@ -59,8 +66,9 @@ class FusedAdamW:
             for b, e in self._ranges(tw):
                 lib().dclip_adamw(tw.flat.data_ptr() + b * 4, tw.flat_grad.data_ptr() + b * 4, m.data_ptr() + b * 4,
                                   v.data_ptr() + b * 4, e - b, self.lr, self.betas[0], self.betas[1], self.eps,
-                                  self.weight_decay, self.step_count, st)
+                                  self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
             tw.wcache_dirty = True
+            tw._grad_clean = bool(zero_grad) and self._ranges_cover_everything(tw)
 
 
     # ---- torch.optim.AdamW-compatible (de)serialisation: what a Lightning checkpoint stores under 'optimizer_states' ----

@@ -154,8 +154,8 @@ int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, floa
                             int64_t vocab, void* stream);
 int dclip_pick_index(const int64_t* ids, int64_t id_stride, int32_t* idx, int64_t B, int64_t N, void* stream);
 int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D, void* stream);
-int dclip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                float weight_decay, int64_t step, void* stream);
+int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int64_t step, int zero_grad, void* stream);   /* zero_grad: g := 0 once consumed */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused distillation loss, forward + backward.

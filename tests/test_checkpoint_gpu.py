@@ -179,3 +179,17 @@ def test_norm_true_pre_normalised_representations():
     assert abs(loss.item() - ref.item()) <= 2e-2 * abs(ref.item()) + 1e-6, (loss.item(), ref.item())
     g, w = dict(m.student.image_encoder.named_parameters())['head.weight'].grad.cpu(), sd_i['head.weight'].grad
     assert (g - w).norm().item() <= 8e-2 * w.norm().item()
+
+
+def test_adamw_clears_consumed_gradients():
+    """FusedAdamW.step(zero_grad=True): same update as step() + zero_grad(), gradients left at zero, later zero_grad() free"""
+    m1, o1, _ = _dual(21)
+    m2, o2, _ = _dual(21)
+    for i in range(2):
+        o1.zero_grad(); l1 = m1.training_step(_batch(i)); m1.backward_and_sync(l1); o1.step()
+        o2.zero_grad(); l2 = m2.training_step(_batch(i)); m2.backward_and_sync(l2); o2.step(zero_grad=True)
+        for tw in m2.towers():
+            assert tw._grad_clean and float(tw.flat_grad.abs().max()) == 0.0
+    a, b = m1.student.state_dict(), m2.student.state_dict()
+    for k in a:
+        assert (a[k] - b[k]).norm().item() <= 2e-4 * (a[k].norm().item() + 1e-12), k
