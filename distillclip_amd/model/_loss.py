@@ -137,31 +137,47 @@ class LossCalculator(nn.Module):
             assert self.temperature, 'You should give the temperature for the kl loss'     # reference :133,:166
         return w
 
+    def _scale_vector(self, device):
+        """loss_scale of each raw term in the kernel's 16-slot output order (cached on the device; rebuilt when the scales change)"""
+        key = (str(device), tuple(sorted(self.loss_scale.items())))
+        if getattr(self, '_scale_cache', (None,))[0] != key:
+            v = [1.0] * 16
+            for n, s in self.loss_scale.items():
+                if n in _SLOT_TOWER:
+                    v[_SLOT_TOWER[n]] = v[_SLOT_TOWER[n] + 4] = float(s)
+                elif n in _SLOT_CROSS:
+                    v[_SLOT_CROSS[n]] = float(s)
+            self._scale_cache = (key, torch.tensor(v, dtype=torch.float32, device=device))
+        return self._scale_cache[1]
+
     def cal_tow_tower_loss(self, stu_out, tea_out):
         loss, scal = _FusedLossFn.apply(stu_out.visual_output.last_representation, stu_out.text_output.last_representation,
                                         tea_out.visual_output.last_representation, tea_out.text_output.last_representation,
                                         self._weights(True), self.temperature, self.global_negatives)
         res = {}
-        for prefix, off, so, to in (('image_', 0, stu_out.visual_output, tea_out.visual_output),
+        scaled = scal * self._scale_vector(scal.device)          # ONE launch for every logged term (they sit between the
+        for prefix, off, so, to in (('image_', 0, stu_out.visual_output, tea_out.visual_output),   # forward and the backward)
                                     ('text_', 4, stu_out.text_output, tea_out.text_output)):
             for n in self.loss_name:
                 if n in _TOWER_FUSED:
-                    res[prefix + n] = scal[_SLOT_TOWER[n] + off] * self.loss_scale[n]
+                    res[prefix + n] = scaled[_SLOT_TOWER[n] + off]
             ft, fres = self._feature_terms(so, to)
-            loss = loss + 0.5 * ft                                       # reference :148: 0.5 * (image_loss + text_loss)
+            if torch.is_tensor(ft):
+                loss = loss + 0.5 * ft                                   # reference :148: 0.5 * (image_loss + text_loss)
             res.update({prefix + k: v for k, v in fres.items()})
         for n in self.loss_name:
             if n in _CROSS_FUSED:
-                res[n] = scal[_SLOT_CROSS[n]] * self.loss_scale[n]
+                res[n] = scaled[_SLOT_CROSS[n]]
         return loss, res
 
     def cal_one_tower_loss(self, stu_out, tea_out):
         loss, scal = _FusedLossFn.apply(stu_out.last_representation, None, tea_out.last_representation, None,
                                         self._weights(False), self.temperature)
-        res = {n: scal[_SLOT_TOWER[n]] * self.loss_scale[n] for n in self.loss_name if n in _TOWER_FUSED}
+        scaled = scal * self._scale_vector(scal.device)
+        res = {n: scaled[_SLOT_TOWER[n]] for n in self.loss_name if n in _TOWER_FUSED}
         ft, fres = self._feature_terms(stu_out, tea_out)
         res.update(fres)
-        return loss + ft, res
+        return (loss + ft) if torch.is_tensor(ft) else loss, res
 
     def forward(self, stu_out, tea_out, model_type: str):
         if model_type == 'all':

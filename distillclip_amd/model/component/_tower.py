@@ -57,8 +57,22 @@ class HipTower:
 
     # ---- parameter plumbing -------------------------------------------------------------------------------------
     def _params(self):
+        """reference-named parameters in the canonical order of include/dclip.h.  The module tree of a tower never changes
+        after construction (load_state_dict / .cuda() keep the Parameter objects), so names are resolved once; a replaced
+        Parameter object is caught by an identity check of the first one (looked up through its owning sub-module)."""
+        cached = getattr(self, '_plist', None)
+        if cached is not None and self._first_owner._parameters.get(self._first_key) is self._first_param:
+            return cached
         table = dict(self.module.named_parameters())
-        return [None if n is None else table[n] for n in self.param_names]
+        plist = [None if n is None else table[n] for n in self.param_names]
+        first = next(n for n in self.param_names if n is not None)
+        owner = self.module
+        *path, key = first.split('.')
+        for part in path:
+            owner = getattr(owner, part)
+        self._first_owner, self._first_key, self._first_param = owner, key, owner._parameters.get(key)
+        self._plist = plist
+        return plist
 
     def materialize(self, device):
         """(Re)build the flat buffers when the parameters are not (any more) views of them (first use, .to(), .cuda())."""
@@ -101,6 +115,13 @@ class HipTower:
         """Make p.grad views of the flat gradient buffer.  If any trainable p.grad was dropped (zero_grad(set_to_none)),
         the buffer is zeroed first — the kernels accumulate with +=, like autograd does into an existing .grad."""
         live = [p for p in self._params() if p is not None]
+        # fast path (every step after the first): first and last trainable parameters still view the flat buffer
+        tr = getattr(self, '_attached', None)
+        if tr is not None and tr[0] == self.flat_grad.data_ptr():
+            pa, pb = tr[1], tr[2]
+            if pa.grad is not None and pb.grad is not None and pa.grad.data_ptr() == tr[3] and pb.grad.data_ptr() == tr[4] \
+                    and tr[5] == sum(1 for p in live if p.requires_grad):
+                return
         fresh = any(p.requires_grad and p.grad is None for p in live)
         if fresh:
             self.flat_grad.zero_()
@@ -109,6 +130,9 @@ class HipTower:
                 want = self.flat_grad.data_ptr() + off * 4
                 if p.grad is None or p.grad.data_ptr() != want:
                     p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+        trainable = [p for p in live if p.requires_grad]
+        self._attached = (self.flat_grad.data_ptr(), trainable[0], trainable[-1], trainable[0].grad.data_ptr(),
+                          trainable[-1].grad.data_ptr(), len(trainable)) if trainable else None
 
     def _ensure_workspace(self, batch, training, device):
         key = (batch, bool(training))
