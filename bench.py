@@ -139,12 +139,13 @@ def main():
     model.set_text_length_hint(tt_tokens if args.teacher_text_prefix else None)
 
     FUSED_ZERO = os.environ.get('DCLIP_BENCH_FUSED_ZERO', '1') != '0'
+    OVERLAP_OPT = os.environ.get('DCLIP_BENCH_OVERLAP_OPT', '1') != '0'   # per-tower optimizer step on the tower's own stream
 
     def step():
         loss = model.training_step([image, text])
         opt.zero_grad()
         model.backward_and_sync(loss)
-        opt.step(zero_grad=FUSED_ZERO)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
+        opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
         return loss
 
     def barrier():

@@ -44,6 +44,11 @@ class HipTower:
         self._saved_batch = None
         self.bwd_done = None
         self._grad_clean = False                  # True after an optimizer step that cleared the gradients it consumed
+        self.bwd_stream = None
+        self.grads_ready = None
+        # trainable towers re-cast their bf16 weight cache at every forward unless an optimizer that maintains
+        # `wcache_dirty` itself (FusedAdamW) has taken over; any other in-place update of the masters needs the re-cast
+        self._prepare_always = True
         # load_state_dict copies into the flat buffer in place: frozen towers must re-cast their bf16 weight cache afterwards
         module.register_load_state_dict_post_hook(lambda m, incompatible: setattr(self, 'wcache_dirty', True))
 
@@ -158,7 +163,7 @@ class HipTower:
         x = x.contiguous()
         self.materialize(x.device)
         B = x.shape[0]
-        if training or self.wcache_dirty or any(p.requires_grad for p in self.module.parameters()):
+        if self.wcache_dirty or (self._prepare_always and (training or any(p.requires_grad for p in self.module.parameters()))):
             self.prepare()      # trainable towers: the optimizer moved the f32 masters since the last cast
         self._ensure_workspace(B, training, x.device)
         out = torch.empty((B, self.cfg.out_dim), dtype=torch.float32, device=x.device)
@@ -204,7 +209,9 @@ class HipTower:
         # whole backward pass): the image tower's all-reduce overlaps the (longer) text tower backward
         if self.bwd_done is None:
             self.bwd_done = torch.cuda.Event()
-        self.bwd_done.record(torch.cuda.current_stream())
+        self.bwd_stream = torch.cuda.current_stream()
+        self.bwd_done.record(self.bwd_stream)
+        self.grads_ready = None                    # set by the gradient exchange (event after this tower's all-reduce)
 
 
 class _TowerFn(torch.autograd.Function):

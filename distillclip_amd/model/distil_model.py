@@ -73,7 +73,8 @@ class DistillModel(nn.Module):
         loss.backward()
         if self._sync is None:
             self._sync = GradSync()
-        self._sync.launch(self.student._tower.flat_grad, after=self.student._tower.bwd_done)
+        tw = self.student._tower
+        tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
         self._sync.wait()
 
     def _acc(self, log, rows, cols, section, prefix, acc=True, score=False):

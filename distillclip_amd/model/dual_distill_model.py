@@ -129,7 +129,7 @@ class DualDistillModel(nn.Module):
         if self._sync is None:
             self._sync = GradSync()
         for tw in self.towers():
-            self._sync.launch(tw.flat_grad, after=tw.bwd_done)
+            tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
         self._sync.wait()
 
     def _acc(self, log, img, txt, section, prefix, acc=True, score=False):

@@ -25,6 +25,9 @@ class FusedAdamW:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = 0
         self._state = {}
+        # overlap mode only: also re-cast the bf16 weight cache right after the update.  Off by default: the re-cast of the NEXT
+        # forward runs under the teacher towers' forward (4 streams wide), which hides it better than the end of the step does
+        self.refresh_cache_in_step = False
 
     def _ranges(self, tw):
         """contiguous [begin, end) element ranges of trainable parameters inside tw.flat"""
@@ -50,12 +53,18 @@ class FusedAdamW:
         return len(r) == 1 and r[0][0] == 0 and r[0][1] >= tw.flat.numel()
 
     @torch.no_grad()
-    def step(self, zero_grad=False):
+    def step(self, zero_grad=False, overlap=False):
         """zero_grad=True: the kernel clears each gradient element once it has consumed it (saves the separate 306 MB fill that
         otherwise runs alone on the main stream); the next zero_grad() is then free.  Frozen ranges are never written by the
-        backward, so a fully trainable tower stays clean until its next backward."""
+        backward, so a fully trainable tower stays clean until its next backward.
+
+        overlap=True: each tower is updated on the stream its backward ran on, as soon as that backward (and, under data
+        parallelism, that tower's gradient all-reduce) is done, followed by the re-cast of its bf16 weight cache — the shorter
+        tower's update then runs under the longer tower's backward instead of alone at the end of the step.  The current stream
+        is ordered after every tower's update before step() returns."""
         self.step_count += 1
-        st = torch.cuda.current_stream().cuda_stream
+        main = torch.cuda.current_stream()
+        joined = []
         for tw in self.towers:
             if tw.flat is None:
                 continue
@@ -63,13 +72,26 @@ class FusedAdamW:
             if key not in self._state or self._state[key][0].numel() != tw.flat.numel():
                 self._state[key] = (torch.zeros_like(tw.flat), torch.zeros_like(tw.flat))
             m, v = self._state[key]
-            for b, e in self._ranges(tw):
-                lib().dclip_adamw(tw.flat.data_ptr() + b * 4, tw.flat_grad.data_ptr() + b * 4, m.data_ptr() + b * 4,
-                                  v.data_ptr() + b * 4, e - b, self.lr, self.betas[0], self.betas[1], self.eps,
-                                  self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
-            tw.wcache_dirty = True
-            tw._grad_clean = bool(zero_grad) and self._ranges_cover_everything(tw)
-
+            stream = tw.bwd_stream if (overlap and getattr(tw, 'bwd_stream', None) is not None) else main
+            if stream != main:
+                stream.wait_stream(main)                     # whatever the caller enqueued before step() (e.g. zero_grad of others)
+                if getattr(tw, 'grads_ready', None) is not None:
+                    stream.wait_event(tw.grads_ready)        # this tower's gradient average (RCCL side stream)
+            with torch.cuda.stream(stream):
+                st = stream.cuda_stream
+                for b, e in self._ranges(tw):
+                    lib().dclip_adamw(tw.flat.data_ptr() + b * 4, tw.flat_grad.data_ptr() + b * 4, m.data_ptr() + b * 4,
+                                      v.data_ptr() + b * 4, e - b, self.lr, self.betas[0], self.betas[1], self.eps,
+                                      self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
+                tw.wcache_dirty = True
+                tw._grad_clean = bool(zero_grad) and self._ranges_cover_everything(tw)
+                if overlap and self.refresh_cache_in_step:
+                    tw._prepare_always = False               # from now on this optimizer keeps the bf16 cache in step
+                    tw.prepare()
+            if stream != main:
+                joined.append(stream)
+        for stream in joined:
+            main.wait_stream(stream)
 
     # ---- torch.optim.AdamW-compatible (de)serialisation: what a Lightning checkpoint stores under 'optimizer_states' ----
     def _slots(self, params=None):

@@ -21,7 +21,7 @@ class GradSync:
         """average `flat_grad` across ranks, asynchronously with respect to the compute stream.  `after`: CUDA event that
         marks the buffer complete (a tower's end-of-backward event); default = everything enqueued on the current stream."""
         if not self.enabled or flat_grad is None:
-            return
+            return None
         if flat_grad.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
@@ -34,6 +34,9 @@ class GradSync:
                     chunk = flat_grad[b:b + self.bucket]
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG)      # RCCL averages in the collective itself
             self._pending.append(flat_grad)
+            done = torch.cuda.Event()
+            done.record(self._stream)              # this buffer's average is complete: a per-tower optimizer step may wait on it
+            return done
         else:   # gloo / CPU rehearsal of the same call pattern
             for b in range(0, flat_grad.numel(), self.bucket):
                 chunk = flat_grad[b:b + self.bucket]
