@@ -141,10 +141,22 @@ def main():
     FUSED_ZERO = os.environ.get('DCLIP_BENCH_FUSED_ZERO', '1') != '0'
     OVERLAP_OPT = os.environ.get('DCLIP_BENCH_OVERLAP_OPT', '1') != '0'   # per-tower optimizer step on the tower's own stream
 
+    PIPE_TEACHER = os.environ.get('DCLIP_BENCH_PIPELINE_TEACHER', '0') == '1'
+    pending = {'teacher': None}
+
     def step():
-        loss = model.training_step([image, text])
-        opt.zero_grad()
-        model.backward_and_sync(loss)
+        if PIPE_TEACHER:
+            # the frozen teacher of the NEXT batch runs under this batch's student backward (same work per step, same values)
+            handle = pending['teacher'] or model.teacher_forward_async([image, text])
+            loss = model.training_step([image, text], teacher=handle)
+            opt.zero_grad()
+            loss.backward()
+            pending['teacher'] = model.teacher_forward_async([image, text])
+            model.backward_and_sync(None)
+        else:
+            loss = model.training_step([image, text])
+            opt.zero_grad()
+            model.backward_and_sync(loss)
         opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
         return loss
 

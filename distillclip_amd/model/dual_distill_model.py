@@ -73,25 +73,56 @@ class DualDistillModel(nn.Module):
     def towers(self):
         return [self.student.image_encoder._tower, self.student.text_encoder._tower]
 
-    def forward(self, inputs) -> Tuple[CLIPOutput, CLIPOutput]:
+    def _tower_streams(self):
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream() for _ in range(4)]
+        return self._streams
+
+    @torch.no_grad()
+    def teacher_forward_async(self, inputs):
+        """Issue the frozen teacher towers for a batch on their two streams WITHOUT joining the current stream, and return a
+        handle for `forward(inputs, teacher=handle)`.  The teacher does not depend on the student, so a training loop may call this
+        for batch t+1 right after `loss.backward()` of batch t: the teacher's forward then runs under the students' backward (the
+        reference computes it inside the same forward, dual_distill_model.py:109; the values are identical)."""
+        image, text = inputs
+        main = torch.cuda.current_stream()
+        streams = self._tower_streams()
+        co = self.need_return_para
+        outs, events = [], []
+        for st, enc, x in ((streams[0], self.teacher.image_encoder, image), (streams[1], self.teacher.text_encoder, text)):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                o = enc(x, co)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            outs.append(o)
+            events.append(ev)
+        return CLIPOutput(visual_output=outs[0], text_output=outs[1]), events
+
+    def forward(self, inputs, teacher=None) -> Tuple[CLIPOutput, CLIPOutput]:
         # reference :106-112.  The batch is (image, text) while CLIPModel.forward takes (text, image).
         image, text = inputs
         if not (self.multi_stream and image.is_cuda):
             student_outs = self.student(text, image, self.need_return_para)
-            with torch.no_grad():  # the reference only relies on requires_grad=False; values are identical
-                teacher_outs = self.teacher(text, image, self.need_return_para)
+            if teacher is not None:
+                teacher_outs, events = teacher
+                for ev in events:
+                    torch.cuda.current_stream().wait_event(ev)
+            else:
+                with torch.no_grad():  # the reference only relies on requires_grad=False (SURVEY.md A8); values are identical
+                    teacher_outs = self.teacher(text, image, self.need_return_para)
         else:
             # The four towers are independent until the loss: issue each on its own HIP stream so their kernels fill each
             # other's tail waves and hide the latency-bound attention kernels.  autograd replays each tower's backward on
             # the stream its forward ran on, so the two student backwards overlap as well.
             main = torch.cuda.current_stream()
-            if self._streams is None:
-                self._streams = [torch.cuda.Stream() for _ in range(4)]
+            streams = self._tower_streams()
             co = self.need_return_para
-            jobs = ((self.teacher.image_encoder, image, False), (self.teacher.text_encoder, text, False),
-                    (self.student.image_encoder, image, True), (self.student.text_encoder, text, True))
+            jobs = [(streams[2], self.student.image_encoder, image, True), (streams[3], self.student.text_encoder, text, True)]
+            if teacher is None:
+                jobs = [(streams[0], self.teacher.image_encoder, image, False), (streams[1], self.teacher.text_encoder, text, False)] + jobs
             outs = []
-            for st, (enc, x, grad) in zip(self._streams, jobs):
+            for st, enc, x, grad in jobs:
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     if grad:
@@ -99,12 +130,18 @@ class DualDistillModel(nn.Module):
                     else:
                         with torch.no_grad():
                             o = enc(x, co)
+                outs.append(o)
+            for st, *_ in jobs:
+                main.wait_stream(st)
+            if teacher is not None:
+                teacher_outs, events = teacher
+                for ev in events:
+                    main.wait_event(ev)
+                outs = [teacher_outs.visual_output, teacher_outs.text_output] + outs
+            for o in outs:
                 for t_ in [o.last_representation, o.embedding] + list(o.representations or []):
                     if t_ is not None:
                         t_.record_stream(main)
-                outs.append(o)
-            for st in self._streams:
-                main.wait_stream(st)
             teacher_outs = CLIPOutput(visual_output=outs[0], text_output=outs[1])
             student_outs = CLIPOutput(visual_output=outs[2], text_output=outs[3])
         if self.hparams.norm:
@@ -114,10 +151,10 @@ class DualDistillModel(nn.Module):
                     o.last_representation = o.last_representation / o.last_representation.norm(dim=-1, keepdim=True)
         return student_outs, teacher_outs
 
-    def training_step(self, inputs, batch_idx=0):
-        # reference :120-127
+    def training_step(self, inputs, batch_idx=0, teacher=None):
+        # reference :120-127 ; `teacher`: optional handle from teacher_forward_async(inputs) issued earlier
         self.teacher.eval()
-        student_outs, teacher_outs = self.forward(inputs)
+        student_outs, teacher_outs = self.forward(inputs, teacher)
         loss, cal_res = self.loss_control(student_outs, teacher_outs, 'all')
         self.last_cal_res = cal_res
         return loss
@@ -125,7 +162,8 @@ class DualDistillModel(nn.Module):
     def backward_and_sync(self, loss):
         """loss.backward() + DDP gradient averaging (reference strategy ddp_find_unused_parameters_false, l_clip.yaml:56).
         Each tower's flat gradient buffer is exchanged on a side stream right after its backward has been enqueued."""
-        loss.backward()
+        if loss is not None:                                   # None: the caller already ran loss.backward()
+            loss.backward()
         if self._sync is None:
             self._sync = GradSync()
         for tw in self.towers():

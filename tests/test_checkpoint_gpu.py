@@ -214,3 +214,26 @@ def test_overlapped_per_tower_optimizer_step_matches_plain():
     sd = m2.student.state_dict()
     m2.student.load_state_dict(sd)
     assert all(tw.wcache_dirty for tw in m2.towers())
+
+
+def test_teacher_issued_ahead_gives_the_same_step():
+    """DualDistillModel.teacher_forward_async + training_step(teacher=handle): the frozen teacher may be issued earlier (e.g. under
+    the previous backward); loss and gradients equal the in-step teacher forward"""
+    m, opt, _ = _dual(31)
+    batch = _batch(3)
+    opt.zero_grad()
+    l1 = m.training_step(batch)
+    l1.backward()
+    g1 = {n: p.grad.detach().clone() for n, p in m.student.named_parameters()}
+    opt.zero_grad()
+    handle = m.teacher_forward_async(batch)
+    l2 = m.training_step(batch, teacher=handle)
+    l2.backward()
+    torch.cuda.synchronize()
+    assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+    for n, p in m.student.named_parameters():
+        assert (p.grad - g1[n]).norm().item() <= 2e-4 * (g1[n].norm().item() + 1e-12), n
+    m.multi_stream = False
+    opt.zero_grad()
+    l3 = m.training_step(batch, teacher=m.teacher_forward_async(batch))
+    assert abs(l1.item() - l3.item()) <= 1e-6 * abs(l1.item())
