@@ -152,12 +152,12 @@ def main():
             opt.zero_grad()
             loss.backward()
             pending['teacher'] = model.teacher_forward_async([image, text])
-            model.backward_and_sync(None)
+            model.backward_and_sync(None, defer_wait=OVERLAP_OPT)
         else:
             loss = model.training_step([image, text])
             opt.zero_grad()
-            model.backward_and_sync(loss)
-        opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
+            model.backward_and_sync(loss, defer_wait=OVERLAP_OPT)
+        opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT, join=not OVERLAP_OPT)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
         return loss
 
     def barrier():

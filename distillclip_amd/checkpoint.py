@@ -28,6 +28,8 @@ def trainable_parameters(model):
 
 
 def checkpoint_dict(model, optimizer=None, scheduler=None, epoch=0, global_step=0):
+    if optimizer is not None and hasattr(optimizer, 'join'):
+        optimizer.join()                         # un-joined per-tower updates must land before the weights are copied
     ckpt = {'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': FORMAT,
             'state_dict': {k: v.detach().to('cpu', copy=True) for k, v in model.state_dict().items()},
             'hyper_parameters': _plain(dict(getattr(model, 'hparams', {})))}

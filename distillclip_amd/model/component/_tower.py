@@ -46,6 +46,7 @@ class HipTower:
         self._grad_clean = False                  # True after an optimizer step that cleared the gradients it consumed
         self.bwd_stream = None
         self.grads_ready = None
+        self.opt_done = None                       # event of an un-joined FusedAdamW.step(overlap=True, join=False)
         # trainable towers re-cast their bf16 weight cache at every forward unless an optimizer that maintains
         # `wcache_dirty` itself (FusedAdamW) has taken over; any other in-place update of the masters needs the re-cast
         self._prepare_always = True
@@ -162,6 +163,9 @@ class HipTower:
             x = x.to(expect)
         x = x.contiguous()
         self.materialize(x.device)
+        ev = getattr(self, 'opt_done', None)
+        if ev is not None:                         # an optimizer update of these weights may still be running on another stream
+            torch.cuda.current_stream().wait_event(ev)
         B = x.shape[0]
         if self.wcache_dirty or (self._prepare_always and (training or any(p.requires_grad for p in self.module.parameters()))):
             self.prepare()      # trainable towers: the optimizer moved the f32 masters since the last cast

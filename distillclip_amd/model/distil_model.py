@@ -68,14 +68,17 @@ class DistillModel(nn.Module):
         self.last_cal_res = cal_res
         return loss
 
-    def backward_and_sync(self, loss):
+    def backward_and_sync(self, loss, defer_wait=False):
         """loss.backward() + the DDP gradient average of the reference's strategy (ddp_find_unused_parameters_false)."""
         loss.backward()
         if self._sync is None:
             self._sync = GradSync()
         tw = self.student._tower
         tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
-        self._sync.wait()
+        if not defer_wait:       # defer_wait: FusedAdamW.step(overlap=True) waits per tower on `grads_ready` instead
+            self._sync.wait()
+        else:
+            self._sync.forget()
 
     def _acc(self, log, rows, cols, section, prefix, acc=True, score=False):
         # reference norm_and_logits :224-231 builds stu_logits = stu_encode @ encode.T : rows = this tower, cols = the other

@@ -159,7 +159,7 @@ class DualDistillModel(nn.Module):
         self.last_cal_res = cal_res
         return loss
 
-    def backward_and_sync(self, loss):
+    def backward_and_sync(self, loss, defer_wait=False):
         """loss.backward() + DDP gradient averaging (reference strategy ddp_find_unused_parameters_false, l_clip.yaml:56).
         Each tower's flat gradient buffer is exchanged on a side stream right after its backward has been enqueued."""
         if loss is not None:                                   # None: the caller already ran loss.backward()
@@ -168,7 +168,10 @@ class DualDistillModel(nn.Module):
             self._sync = GradSync()
         for tw in self.towers():
             tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
-        self._sync.wait()
+        if not defer_wait:       # defer_wait: FusedAdamW.step(overlap=True) waits per tower on `grads_ready` instead
+            self._sync.wait()
+        else:
+            self._sync.forget()
 
     def _acc(self, log, img, txt, section, prefix, acc=True, score=False):
         m = retrieval_metrics(img, txt, self.k_list)

@@ -46,6 +46,7 @@ class FusedAdamW:
     def zero_grad(self, set_to_none=False):
         for tw in self.towers:
             if tw.flat_grad is not None and not getattr(tw, '_grad_clean', False):
+                self.join()
                 tw.flat_grad.zero_()
 
     def _ranges_cover_everything(self, tw):
@@ -53,7 +54,7 @@ class FusedAdamW:
         return len(r) == 1 and r[0][0] == 0 and r[0][1] >= tw.flat.numel()
 
     @torch.no_grad()
-    def step(self, zero_grad=False, overlap=False):
+    def step(self, zero_grad=False, overlap=False, join=True):
         """zero_grad=True: the kernel clears each gradient element once it has consumed it (saves the separate 306 MB fill that
         otherwise runs alone on the main stream); the next zero_grad() is then free.  Frozen ranges are never written by the
         backward, so a fully trainable tower stays clean until its next backward.
@@ -61,7 +62,10 @@ class FusedAdamW:
         overlap=True: each tower is updated on the stream its backward ran on, as soon as that backward (and, under data
         parallelism, that tower's gradient all-reduce) is done, followed by the re-cast of its bf16 weight cache — the shorter
         tower's update then runs under the longer tower's backward instead of alone at the end of the step.  The current stream
-        is ordered after every tower's update before step() returns."""
+        is ordered after every tower's update before step() returns, unless join=False: then only the tower streams carry the
+        dependency (backward -> all-reduce -> update -> next forward of that tower) and the next step's frozen teacher towers
+        may start while the last gradient exchange and update are still running; join() orders the current stream after them
+        (zero_grad() and state_dict() call it)."""
         self.step_count += 1
         main = torch.cuda.current_stream()
         joined = []
@@ -90,8 +94,22 @@ class FusedAdamW:
                     tw.prepare()
             if stream != main:
                 joined.append(stream)
-        for stream in joined:
-            main.wait_stream(stream)
+                tw.opt_done = torch.cuda.Event()
+                tw.opt_done.record(stream)
+        if join:
+            for stream in joined:
+                main.wait_stream(stream)
+            for tw in self.towers:
+                tw.opt_done = None
+
+    def join(self):
+        """order the current stream after every tower's pending (un-joined) update"""
+        cur = torch.cuda.current_stream()
+        for tw in self.towers:
+            ev = getattr(tw, 'opt_done', None)
+            if ev is not None:
+                cur.wait_event(ev)
+                tw.opt_done = None
 
     # ---- torch.optim.AdamW-compatible (de)serialisation: what a Lightning checkpoint stores under 'optimizer_states' ----
     def _slots(self, params=None):
@@ -118,6 +136,7 @@ class FusedAdamW:
     def state_dict(self, params=None):
         """`params`: the iteration order torch.optim.AdamW would have been built with (reference distil_model.py:161,
         dual_distill_model.py:195: filter(requires_grad, self.parameters())); default = canonical tower order."""
+        self.join()
         slots = self._slots(params)
         state = {}
         for i, (tw, off, n, shape) in enumerate(slots):

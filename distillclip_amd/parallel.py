@@ -48,6 +48,10 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self._stream)
         self._pending = []
 
+    def forget(self):
+        """the caller carries the dependency itself (per-buffer events returned by launch)"""
+        self._pending = []
+
 
 def gather_embeddings(tensors):
     """All-gather a list of [B, E] tensors across ranks with ONE collective: -> ([W*B, E] tensors, rank, world).

@@ -237,3 +237,23 @@ def test_teacher_issued_ahead_gives_the_same_step():
     opt.zero_grad()
     l3 = m.training_step(batch, teacher=m.teacher_forward_async(batch))
     assert abs(l1.item() - l3.item()) <= 1e-6 * abs(l1.item())
+
+
+def test_unjoined_overlapped_step_with_deferred_sync_matches_plain():
+    """bench.py's loop: backward_and_sync(defer_wait=True) + step(overlap=True, join=False): dependencies ride on the tower streams
+    only; same trajectory as the plain loop, also across a switch to single-stream towers and through a checkpoint"""
+    from distillclip_amd.checkpoint import checkpoint_dict
+    m1, o1, _ = _dual(29)
+    m2, o2, _ = _dual(29)
+    for i in range(5):
+        if i == 3:
+            m1.multi_stream = m2.multi_stream = False      # the next forward runs on the main stream: it must see the update
+        o1.zero_grad(); l1 = m1.training_step(_batch(i)); m1.backward_and_sync(l1); o1.step()
+        o2.zero_grad(); l2 = m2.training_step(_batch(i)); m2.backward_and_sync(l2, defer_wait=True)
+        o2.step(zero_grad=True, overlap=True, join=False)
+        assert abs(l1.item() - l2.item()) <= 1e-4 * abs(l1.item()), (i, l1.item(), l2.item())
+    ck = checkpoint_dict(m2, o2)                           # joins before copying
+    a = m1.student.state_dict()
+    for k, v in a.items():
+        w = ck['state_dict']['student.' + k]
+        assert (v.cpu() - w).norm().item() <= 5e-4 * (w.norm().item() + 1e-12), k
