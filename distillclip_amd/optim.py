@@ -79,8 +79,9 @@ class FusedAdamW:
             stream = tw.bwd_stream if (overlap and getattr(tw, 'bwd_stream', None) is not None) else main
             if stream != main:
                 stream.wait_stream(main)                     # whatever the caller enqueued before step() (e.g. zero_grad of others)
-                if getattr(tw, 'grads_ready', None) is not None:
-                    stream.wait_event(tw.grads_ready)        # this tower's gradient average (RCCL side stream)
+            if getattr(tw, 'grads_ready', None) is not None:
+                stream.wait_event(tw.grads_ready)            # this tower's gradient average (RCCL side stream), whichever stream updates
+                tw.grads_ready = None
             with torch.cuda.stream(stream):
                 st = stream.cuda_stream
                 for b, e in self._ranges(tw):
