@@ -39,7 +39,9 @@ struct LossArgs {
     float* dsh[2];                            // d loss / d normalised student embedding [zs][B,E] (partials per slice)
     float* scal;                              // [NSC] atomically accumulated
     float* out;                               // [16] user-visible scalars
-    int B, E;
+    int B, E;                                 // B: number of columns = rows of the (gathered) inputs
+    int r0, Bl;                               // the rows this call owns: [r0, r0 + Bl) (whole matrix: 0, B).  Row-block mode:
+                                              // data-parallel ranks evaluate their own row block of the global-negative loss
     LossCfg c;
 };
 
@@ -55,6 +57,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     const int ntow = a.c.two_tower ? 2 : 1;
     const float tw = a.c.two_tower ? 0.5f : 1.f;
     const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
+    const bool own = b >= a.r0 && b < a.r0 + a.Bl;          // rows outside the block only feed the columns (normalised copies)
+    const int bl = b - a.r0;
     for (int tow = 0; tow < ntow; ++tow) {
         const float* sp = a.s[tow] + (int64_t)b * E;
         const float* tp = a.t[tow] + (int64_t)b * E;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
                     }
                     g[k] = gr; sn[k] = s * inv_s; tn[k] = t * inv_t;
                 }
-                *(float4*)(a.ds[tow] + (int64_t)b * E + c) = float4{g[0], g[1], g[2], g[3]};
+                if (own) *(float4*)(a.ds[tow] + (int64_t)bl * E + c) = float4{g[0], g[1], g[2], g[3]};
                 if (cross) {
                     *(float4*)(a.nrm[tow] + (int64_t)b * E + c) = float4{sn[0], sn[1], sn[2], sn[3]};
                     *(float4*)(a.nrm[2 + tow] + (int64_t)b * E + c) = float4{tn[0], tn[1], tn[2], tn[3]};
@@ -134,13 +138,13 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
             }
         }
         kl = wave_sum(kl); ce = wave_sum(ce);
-        if (lane == 0) {
+        if (lane == 0 && own) {
             float* sc = a.scal + (tow ? SC_TXT : SC_IMG);
             unsafeAtomicAdd(sc + 0, l1);
             unsafeAtomicAdd(sc + 1, 1.f - cosv);
             if (a.c.w_kl != 0.f) unsafeAtomicAdd(sc + 2, kl);
             if (a.c.w_ce != 0.f) unsafeAtomicAdd(sc + 3, ce);
-            if (cross) a.inv[tow][b] = inv_s;
+            if (cross) a.inv[tow][bl] = inv_s;
         }
     }
 }
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dir = blockIdx.y;
     const int B = a.B, E = a.E;
-    const int i0 = blockIdx.x * 16;
+    const int i0 = a.r0 + blockIdx.x * 16, iend = a.r0 + a.Bl;   // owned rows (global indices)
     const float* sa = a.nrm[dir], *sb = a.nrm[1 - dir];           // student rows / cols
     const float* ta = a.nrm[2 + dir], *tb = a.nrm[3 - dir];       // teacher rows / cols
     const float itau = a.c.w_sl != 0.f ? 1.f / a.c.tau : 1.f;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = i0 + (lane >> 4) * 4 + q;
-            if (row < B && col < B) {
+            if (row < iend && col < B) {
                 const float s = S[q], t = T[q];
                 if (a.c.w_hl != 0.f) r1[q] += __expf(s - 1.f);
                 if (a.c.w_sl != 0.f) { rs[q] += __expf((s - 1.f) * itau); rt[q] += __expf((t - 1.f) * itau); }
@@ -222,9 +226,9 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
     __syncthreads();
     if (threadIdx.x < 48) {
         const int r = threadIdx.x % 16, k = threadIdx.x / 16;
-        if (i0 + r < B) {
+        if (i0 + r < iend) {
             const float v = (red[0][r][k] + red[1][r][k]) + (red[2][r][k] + red[3][r][k]);
-            a.stats[((int64_t)z * 6 + dir * 3 + k) * B + i0 + r] = v;
+            a.stats[((int64_t)z * 6 + dir * 3 + k) * a.Bl + i0 - a.r0 + r] = v;
         }
     }
 }
@@ -235,26 +239,28 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
     const int dir = blockIdx.y;
     const int B = a.B, E = a.E;
     const int ntile = (B + 15) / 16;
-    const int ldl = ntile * 16 + 4;
-    const int i0 = blockIdx.x * 16;
+    const int ldl = ((ntile + a.zs - 1) / a.zs) * 16 + 4;       // the LDS stripe holds this slice's columns only
+    const int i0 = a.r0 + blockIdx.x * 16, iend = a.r0 + a.Bl;   // owned rows (global indices)
+    const int Bl = a.Bl;
     const float* sa = a.nrm[dir], *sb = a.nrm[1 - dir];
     const float* ta = a.nrm[2 + dir], *tb = a.nrm[3 - dir];
     const float tau = a.c.tau, itau = a.c.w_sl != 0.f ? 1.f / tau : 1.f;
     // row statistics of this direction, column statistics = row statistics of the other direction
-    const float* rst = a.stats + (int64_t)dir * 3 * B;
-    const float* cst = a.stats + (int64_t)(1 - dir) * 3 * B;
+    // (the column statistics exist only when the call owns every row: hard_label / soft_label are not offered in row-block mode)
+    const float* rst = a.stats + (int64_t)dir * 3 * Bl;
+    const float* cst = a.stats + (int64_t)(1 - dir) * 3 * Bl;
     // the row / column sums arrive as one partial per column slice of pass A: added in slice order (deterministic)
     auto stat = [&](const float* base, int idx) {
         float v = 0.f;
-        for (int zz = 0; zz < a.zs; ++zz) v += base[(int64_t)zz * 6 * B + idx];
+        for (int zz = 0; zz < a.zs; ++zz) v += base[(int64_t)zz * 6 * Bl + idx];
         return v;
     };
     const int ia = min(i0 + (lane & 15), B - 1) - (lane & 15);
     float rr1[4], rrs[4], rrt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int row = min(i0 + (lane >> 4) * 4 + q, B - 1);
-        rr1[q] = stat(rst, row); rrs[q] = stat(rst, B + row); rrt[q] = stat(rst, 2 * B + row);
+        const int row = min(i0 + (lane >> 4) * 4 + q, iend - 1) - a.r0;
+        rr1[q] = stat(rst, row); rrs[q] = stat(rst, Bl + row); rrt[q] = stat(rst, 2 * Bl + row);
     }
     const int z = blockIdx.z, t0 = (int)((int64_t)ntile * z / a.zs), t1 = (int)((int64_t)ntile * (z + 1) / a.zs);
     const float k_cd_pos = a.c.w_cd / B, k_cd_neg = B > 1 ? a.c.w_cd / ((float)B * (B - 1)) : 0.f;
@@ -269,12 +275,13 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         const f32x4 T = logits_tile(ta + (int64_t)ia * E, tb + (int64_t)jb * E, E, lane);
         const int col = j0 + (lane & 15);
         const int cc = min(col, B - 1);
-        const float c1 = stat(cst, cc), cs = stat(cst, B + cc), ct = stat(cst, 2 * B + cc);
+        const bool cstat = a.c.w_hl != 0.f || a.c.w_sl != 0.f;      // only then (and only with every row owned) are they read
+        const float c1 = cstat ? stat(cst, cc) : 1.f, cs = cstat ? stat(cst, Bl + cc) : 1.f, ct = cstat ? stat(cst, 2 * Bl + cc) : 1.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rl = (lane >> 4) * 4 + q, row = i0 + rl;
             float d = 0.f;
-            if (row < B && col < B) {
+            if (row < iend && col < B) {
                 const float s = S[q], t = T[q];
                 // cos_diff (clip_cos_diff.py:16-23) and logits_mse: identical in both directions -> one full share
                 if (row == col) d -= (t > s) ? k_cd_pos : 0.f;
@@ -292,27 +299,27 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
                     klacc += (et / rrt[q]) * (lpt - lps);
                 }
             }
-            dsl[rl * ldl + col] = d;
+            dsl[rl * ldl + col - t0 * 16] = d;
         }
     }
     if (a.c.w_sl != 0.f) {
         klacc = wave_sum(klacc);
         if (lane == 0) unsafeAtomicAdd(a.scal + (dir ? SC_KL1 : SC_KL0), klacc);
     }
-    if (a.c.w_hl != 0.f && z == 0 && wave == 0 && lane < 16 && i0 + lane < B)
-        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(stat(rst, i0 + lane)) + 1.f);
+    if (a.c.w_hl != 0.f && z == 0 && wave == 0 && lane < 16 && i0 + lane < iend)
+        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(stat(rst, i0 - a.r0 + lane)) + 1.f);
     __syncthreads();
     // gradient rows: G[16, E] = dS_stripe[16, B] @ Y[B, E],  Y = normalised student embedding of the other modality
     // (this slice's columns only: the slices' partial rows are added in loss_finalize_kernel)
     const float* Y = sb;
-    float* G = a.dsh[dir] + (int64_t)z * B * E;
+    float* G = a.dsh[dir] + (int64_t)z * Bl * E;
     const float* arow = dsl + (lane & 15) * ldl + (lane >> 4) * 4;
     for (int e0 = wave * 16; e0 < E; e0 += 64) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* yb = Y + e0 + (lane & 15);
-        for (int o = t0 * 16; o < t1 * 16; o += 16) {
+        for (int o = 0; o < (t1 - t0) * 16; o += 16) {
             const float4 av = *(const float4*)(arow + o);
-            const int k0 = o + (lane >> 4) * 4;
+            const int k0 = t0 * 16 + o + (lane >> 4) * 4;
             // rows beyond B carry zero weights in dsl; clamp the address only
             const float b0 = yb[(int64_t)min(k0 + 0, B - 1) * E], b1 = yb[(int64_t)min(k0 + 1, B - 1) * E];
             const float b2 = yb[(int64_t)min(k0 + 2, B - 1) * E], b3 = yb[(int64_t)min(k0 + 3, B - 1) * E];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = i0 + (lane >> 4) * 4 + q;
-            if (row < B) G[(int64_t)row * E + e0 + (lane & 15)] = acc[q];
+            if (row < iend) G[(int64_t)(row - a.r0) * E + e0 + (lane & 15)] = acc[q];
         }
     }
 }
@@ -332,12 +339,12 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
 // normalisation backward: x_hat = x / |x|  =>  dx = (g - x_hat (x_hat . g)) / |x| ; added to the tower-term gradient
 __global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);          // owned row (local index)
+    if (b >= a.Bl) return;
     for (int tow = 0; tow < 2; ++tow) {
-        const float* xh = a.nrm[tow] + (int64_t)b * a.E;
+        const float* xh = a.nrm[tow] + (int64_t)(a.r0 + b) * a.E;
         float* g = a.dsh[tow] + (int64_t)b * a.E;
-        const int64_t zstride = (int64_t)a.B * a.E;
+        const int64_t zstride = (int64_t)a.Bl * a.E;
         float dot = 0.f;
         for (int c = lane * 4; c < a.E; c += 256) {
             float4 y = *(const float4*)(g + c);
@@ -394,74 +401,94 @@ __global__ void loss_total_kernel(LossArgs a) {
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// column slices of the stripe kernels: 2 * ceil(B / 16) stripes alone fill 64 of the 256 CUs at B = 512, and the loss sits
-// alone on the critical path between the forward and the backward
-inline int loss_slices(int64_t B) {
-    const int ntile = (int)((B + 15) / 16);
-    int zs = 256 / (2 * ntile);
-    zs = zs < 1 ? 1 : (zs > 8 ? 8 : zs);
-    return zs > ntile ? ntile : zs;
-}
-
 }  // namespace
 
 extern "C" size_t dclip_distill_loss_workspace(int64_t B, int64_t E) {
     const size_t be = align_up((size_t)B * E * sizeof(float));
-    const size_t zs = (size_t)loss_slices(B);
+    const size_t zs = 8;                                     // upper bound of loss_slices() for any row block
     return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up(NSC * 4);
 }
 
-extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B,
-                                  int64_t E, const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt,
-                                  void* workspace, size_t ws_bytes, void* stream) {
-    DCLIP_REQUIRE(cfg && out_scalars && workspace, "dclip_distill_loss: null argument");
+namespace {
+
+int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B, int64_t E,
+                     int64_t row0, int64_t rows, const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt,
+                     void* workspace, size_t ws_bytes, void* stream, const char* who) {
+    DCLIP_REQUIRE(cfg && out_scalars && workspace, "%s: null argument", who);
     LossArgs a;
     a.c.w_l1 = cfg[0]; a.c.w_cos = cfg[1]; a.c.w_kl = cfg[2]; a.c.w_ce = cfg[3];
     a.c.w_cd = cfg[4]; a.c.w_hl = cfg[5]; a.c.w_sl = cfg[6]; a.c.w_mse = cfg[7];
     a.c.tau = cfg[8]; a.c.two_tower = cfg[9] != 0.f;
-    DCLIP_REQUIRE(s_img && t_img && d_s_img, "dclip_distill_loss: tower 0 pointers are required");
-    DCLIP_REQUIRE(!a.c.two_tower || (s_txt && t_txt && d_s_txt), "dclip_distill_loss: two-tower mode needs both towers");
-    DCLIP_REQUIRE(B > 0 && E > 0 && E % 16 == 0 && E <= 1024, "dclip_distill_loss: need E %% 16 == 0, E <= 1024 (E=%ld)", (long)E);
-    DCLIP_REQUIRE(B <= 4096, "dclip_distill_loss: B <= 4096 (stripe LDS budget), got %ld", (long)B);
-    DCLIP_REQUIRE((a.c.w_kl == 0.f && a.c.w_sl == 0.f) || a.c.tau > 0.f, "dclip_distill_loss: KL terms need temperature > 0");
-    DCLIP_REQUIRE(ws_bytes >= dclip_distill_loss_workspace(B, E), "dclip_distill_loss: workspace too small");
-    DCLIP_REQUIRE(((uintptr_t)workspace % 256) == 0, "dclip_distill_loss: workspace must be 256-byte aligned");
+    DCLIP_REQUIRE(s_img && t_img && d_s_img, "%s: tower 0 pointers are required", who);
+    DCLIP_REQUIRE(!a.c.two_tower || (s_txt && t_txt && d_s_txt), "%s: two-tower mode needs both towers", who);
+    DCLIP_REQUIRE(B > 0 && E > 0 && E % 16 == 0 && E <= 1024, "%s: need E %% 16 == 0, E <= 1024 (E=%ld)", who, (long)E);
+    DCLIP_REQUIRE(B <= 4096, "%s: B <= 4096 (stripe LDS budget), got %ld", who, (long)B);
+    DCLIP_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= B, "%s: row block [%ld, %ld) outside [0, %ld)", who, (long)row0, (long)(row0 + rows), (long)B);
+    DCLIP_REQUIRE(rows == B || (a.c.w_hl == 0.f && a.c.w_sl == 0.f),
+                  "%s: hard_label / soft_label need the column statistics of every row: not available for a row block", who);
+    DCLIP_REQUIRE((a.c.w_kl == 0.f && a.c.w_sl == 0.f) || a.c.tau > 0.f, "%s: KL terms need temperature > 0", who);
+    DCLIP_REQUIRE(ws_bytes >= dclip_distill_loss_workspace(B, E), "%s: workspace too small", who);
+    DCLIP_REQUIRE(((uintptr_t)workspace % 256) == 0, "%s: workspace must be 256-byte aligned", who);
     a.s[0] = s_img; a.s[1] = s_txt; a.t[0] = t_img; a.t[1] = t_txt; a.ds[0] = d_s_img; a.ds[1] = d_s_txt;
-    a.B = (int)B; a.E = (int)E; a.out = out_scalars;
+    a.B = (int)B; a.E = (int)E; a.r0 = (int)row0; a.Bl = (int)rows; a.out = out_scalars;
     char* w = (char*)workspace;
     const size_t be = align_up((size_t)B * E * sizeof(float));
     for (int i = 0; i < 4; ++i) { a.nrm[i] = (float*)w; w += be; }
-    a.zs = loss_slices(B);
+    // column slices: enough workgroups for the chip from the owned row stripes
+    {
+        const int rtile = (int)((rows + 15) / 16), ctile = (int)((B + 15) / 16);
+        int zs = 256 / (2 * rtile);
+        zs = zs < 1 ? 1 : (zs > 8 ? 8 : zs);
+        zs = zs > ctile ? ctile : zs;
+        while (zs < 8 && (size_t)16 * (((ctile + zs - 1) / zs) * 16 + 4) * sizeof(float) > 144 * 1024) ++zs;   // LDS stripe budget
+        a.zs = zs;
+    }
     for (int i = 0; i < 2; ++i) { a.dsh[i] = (float*)w; w += (size_t)a.zs * be; }
-    a.inv[0] = (float*)w; a.inv[1] = a.inv[0] + B; w += align_up((size_t)2 * B * 4);
+    a.inv[0] = (float*)w; a.inv[1] = a.inv[0] + rows; w += align_up((size_t)2 * B * 4);
     a.stats = (float*)w; w += align_up((size_t)a.zs * 6 * B * 4);
     a.scal = (float*)w;
     hipStream_t st = (hipStream_t)stream;
-    // algorithmic HBM bytes: read 4*B*E*4 + write 2*B*E*4 ; the [B,B] logits contribute none
-    TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 6.0 : 3.0) * (double)B * E * 4.0, stream);
+    // algorithmic HBM bytes: read 4*B*E*4 + write 2*rows*E*4 ; the logits contribute none
+    TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 2.0 : 1.0) * (2.0 * (double)B + (double)rows) * E * 4.0, stream);
     if (hipMemsetAsync(a.scal, 0, NSC * sizeof(float), st) != hipSuccess) {
-        dclip_set_error("dclip_distill_loss: memset failed");
+        dclip_set_error("%s: memset failed", who);
         return DCLIP_ELAUNCH;
     }
-    const dim3 rows((unsigned)((B + 3) / 4));
+    const dim3 allrows((unsigned)((B + 3) / 4)), ownrows((unsigned)((rows + 3) / 4));
     const int nv = (int)((E + 255) / 256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL((loss_rows_kernel<1>), rows, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((loss_rows_kernel<2>), rows, dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((loss_rows_kernel<3>), rows, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((loss_rows_kernel<4>), rows, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((loss_rows_kernel<1>), allrows, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((loss_rows_kernel<2>), allrows, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((loss_rows_kernel<3>), allrows, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((loss_rows_kernel<4>), allrows, dim3(256), 0, st, a); break;
     }
     const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
     if (cross) {
-        const dim3 grid((unsigned)((B + 15) / 16), 2, (unsigned)a.zs);
+        const dim3 grid((unsigned)((rows + 15) / 16), 2, (unsigned)a.zs);
         hipLaunchKernelGGL(loss_stripe_a_kernel, grid, dim3(256), 0, st, a);
-        const size_t lds = (size_t)16 * (((B + 15) / 16) * 16 + 4) * sizeof(float);
-        DCLIP_REQUIRE(lds <= 160 * 1024, "dclip_distill_loss: stripe does not fit LDS");
+        const size_t lds = (size_t)16 * (((((B + 15) / 16) + a.zs - 1) / a.zs) * 16 + 4) * sizeof(float);
+        DCLIP_REQUIRE(lds <= 160 * 1024, "%s: stripe does not fit LDS", who);
         hipLaunchKernelGGL(loss_stripe_b_kernel, grid, dim3(256), lds, st, a);
-        hipLaunchKernelGGL(loss_finalize_kernel, rows, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_finalize_kernel, ownrows, dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a);
-    return dclip_check_launch("dclip_distill_loss");
+    return dclip_check_launch(who);
+}
+
+}  // namespace
+
+extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B,
+                                  int64_t E, const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt,
+                                  void* workspace, size_t ws_bytes, void* stream) {
+    return run_distill_loss(s_img, t_img, s_txt, t_txt, B, E, 0, B, cfg, out_scalars, d_s_img, d_s_txt, workspace, ws_bytes, stream,
+                            "dclip_distill_loss");
+}
+
+extern "C" int dclip_distill_loss_rows(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B,
+                                       int64_t E, int64_t row0, int64_t rows, const float* cfg, float* out_scalars,
+                                       float* d_s_img, float* d_s_txt, void* workspace, size_t ws_bytes, void* stream) {
+    return run_distill_loss(s_img, t_img, s_txt, t_txt, B, E, row0, rows, cfg, out_scalars, d_s_img, d_s_txt, workspace, ws_bytes,
+                            stream, "dclip_distill_loss_rows");
 }
 
 // feature MSE (hidden_rep_mse / embedding_mse terms: hidden_mse.py:9-17, embed_mse.py:9-10):

@@ -117,8 +117,10 @@ LOSS_SLOTS = {'out_l1': 0, 'out_cos': 1, 'out_kl': 2, 'out_ce': 3, 'cos_diff': 4
               'logits_mse': 7}
 
 
-def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=None):
-    """Fused loss fwd+bwd.  weights: {term: scale*percent}.  -> (scalars[16] device tensor, d_s_img, d_s_txt)."""
+def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=None, row0=None, rows=None):
+    """Fused loss fwd+bwd.  weights: {term: scale*percent}.  -> (scalars[16] device tensor, d_s_img, d_s_txt).
+    row0 / rows: evaluate only the row block [row0, row0 + rows) of the (gathered) batch against all columns — gradients
+    [rows, E] of the owned samples, scalars = this block's share (sum over the blocks = the whole-batch values)."""
     import ctypes
     _chk(s_img, t_img, s_txt, t_txt)
     B, E = s_img.shape
@@ -132,10 +134,15 @@ def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=N
     ws_bytes = lib().dclip_distill_loss_workspace(B, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s_img.device)
     out = torch.empty(16, dtype=torch.float32, device=s_img.device)
-    d_i = torch.empty_like(s_img)
-    d_t = torch.empty_like(s_txt) if two else None
-    lib().dclip_distill_loss(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, ctypes.cast(cfg_arr, ctypes.c_void_p),
-                             _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
+    nrow = B if rows is None else int(rows)
+    d_i = torch.empty((nrow, E), dtype=torch.float32, device=s_img.device)
+    d_t = torch.empty((nrow, E), dtype=torch.float32, device=s_img.device) if two else None
+    if rows is None:
+        lib().dclip_distill_loss(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, ctypes.cast(cfg_arr, ctypes.c_void_p),
+                                 _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
+    else:
+        lib().dclip_distill_loss_rows(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, int(row0), nrow,
+                                      ctypes.cast(cfg_arr, ctypes.c_void_p), _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
     return out, d_i, d_t
 
 

@@ -94,3 +94,41 @@ def test_bad_arguments():
         ops.distill_loss(x, x, weights={'out_l1': 1.0})
     with pytest.raises(RuntimeError):
         ops.distill_loss(x.cpu(), x.cpu(), weights={'out_l1': 1.0})
+
+
+@pytest.mark.parametrize('B,world,names', [(24, 3, ['out_l1', 'out_cos', 'cos_diff']), (64, 4, ['out_cos', 'out_kl', 'cos_diff', 'logits_mse']),
+                                           (512, 8, ['out_l1', 'out_cos', 'cos_diff']),
+                                           (4096, 8, ['out_l1', 'out_cos', 'cos_diff'])])      # 8 ranks x 512: the N = 8 bench shape
+def test_row_blocks_add_up_to_the_whole_batch(B, world, names):
+    """dclip_distill_loss_rows (data-parallel global negatives): every rank's row block [B / world, B] — the scalar shares
+    sum to the whole-batch scalars and the gradient rows equal the whole-batch gradient rows (oracle = single process on the
+    concatenated batch)"""
+    from distillclip_amd import ops
+    E = 512 if B >= 512 else 64
+    g = torch.Generator().manual_seed(B + world)
+    e = {k: (torch.randn(B, E, generator=g) * (1 + i)).cuda() for i, k in enumerate(('si', 'st', 'ti', 'tt'))}
+    e['ti'] = 0.7 * e['ti'] + 0.5 * e['si']
+    scale = {'cos_diff': 0.1}
+    lc = oracle.LossOracle(names, scale, temperature=2.0)
+    w = {n: lc.loss_scale[n] * lc.percent[n] for n in lc.loss_name}
+    full, di, dt = ops.distill_loss(e['si'], e['ti'], e['st'], e['tt'], weights=w, temperature=2.0)
+    per = B // world
+    tot = torch.zeros(16, device='cuda')
+    for r in range(world):
+        sc, gi, gt = ops.distill_loss(e['si'], e['ti'], e['st'], e['tt'], weights=w, temperature=2.0, row0=r * per, rows=per)
+        tot += sc
+        assert _rel(gi, di[r * per:(r + 1) * per]) < 2e-5 and _rel(gt, dt[r * per:(r + 1) * per]) < 2e-5, r
+    assert torch.allclose(tot, full, rtol=2e-5, atol=1e-6), (tot, full)
+    # and against the oracle on the concatenated batch
+    loss, res, ogi, ogt, _ = _run_oracle({k: v.cpu() for k, v in e.items()}, names, scale, 2.0)
+    assert abs(tot[0].item() - loss.item()) <= 2e-5 * max(1.0, abs(loss.item()))
+    assert _rel(di.cpu(), ogi) < 2e-4 and _rel(dt.cpu(), ogt) < 2e-4
+
+
+def test_row_block_rejects_terms_that_need_every_row():
+    from distillclip_amd import ops
+    x = torch.randn(32, 64, device='cuda')
+    with pytest.raises(ValueError):
+        ops.distill_loss(x, x, x, x, weights={'hard_label': 1.0}, row0=0, rows=16)
+    with pytest.raises(ValueError):
+        ops.distill_loss(x, x, x, x, weights={'cos_diff': 1.0}, row0=24, rows=16)
