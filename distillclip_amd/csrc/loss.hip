@@ -34,7 +34,10 @@ struct LossArgs {
     float* ds[2];
     float* nrm[4];                            // normalised s_img, s_txt, t_img, t_txt  [B,E]
     float* inv[2];                            // 1 / |s|
-    float* stats;                             // [zs][6][B]: r1S rtS rtT c1S ctS ctT, one partial per column slice
+    float* stats;                             // [zs][6][Bl]: r1S rtS rtT c1S ctS ctT of the owned rows, one partial per column slice
+    const float* gstats;                      // row-block mode with hard / soft label: [6][B] statistics of EVERY row (all ranks'
+                                              // pass-A results, gathered by the caller); null otherwise
+    float* stats_out;                         // row-block pass-A-only call: [6][Bl] slice-summed statistics for that gather
     int zs;                                   // column slices of the stripe kernels (blockIdx.z): fills the chip at B = 512
     float* dsh[2];                            // d loss / d normalised student embedding [zs][B,E] (partials per slice)
     float* scal;                              // [NSC] atomically accumulated
@@ -255,12 +258,16 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         for (int zz = 0; zz < a.zs; ++zz) v += base[(int64_t)zz * 6 * Bl + idx];
         return v;
     };
+    // with gathered statistics: row k of direction d is a.gstats[(d * 3 + k) * B + global index]
+    const float* grow = a.gstats ? a.gstats + (int64_t)dir * 3 * B : nullptr;
+    const float* gcol = a.gstats ? a.gstats + (int64_t)(1 - dir) * 3 * B : nullptr;
     const int ia = min(i0 + (lane & 15), B - 1) - (lane & 15);
     float rr1[4], rrs[4], rrt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = min(i0 + (lane >> 4) * 4 + q, iend - 1) - a.r0;
-        rr1[q] = stat(rst, row); rrs[q] = stat(rst, Bl + row); rrt[q] = stat(rst, 2 * Bl + row);
+        if (grow) { rr1[q] = grow[a.r0 + row]; rrs[q] = grow[B + a.r0 + row]; rrt[q] = grow[2 * B + a.r0 + row]; }
+        else { rr1[q] = stat(rst, row); rrs[q] = stat(rst, Bl + row); rrt[q] = stat(rst, 2 * Bl + row); }
     }
     const int z = blockIdx.z, t0 = (int)((int64_t)ntile * z / a.zs), t1 = (int)((int64_t)ntile * (z + 1) / a.zs);
     const float k_cd_pos = a.c.w_cd / B, k_cd_neg = B > 1 ? a.c.w_cd / ((float)B * (B - 1)) : 0.f;
@@ -276,7 +283,9 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         const int col = j0 + (lane & 15);
         const int cc = min(col, B - 1);
         const bool cstat = a.c.w_hl != 0.f || a.c.w_sl != 0.f;      // only then (and only with every row owned) are they read
-        const float c1 = cstat ? stat(cst, cc) : 1.f, cs = cstat ? stat(cst, Bl + cc) : 1.f, ct = cstat ? stat(cst, 2 * Bl + cc) : 1.f;
+        float c1 = 1.f, cs = 1.f, ct = 1.f;
+        if (cstat && gcol) { c1 = gcol[cc]; cs = gcol[B + cc]; ct = gcol[2 * B + cc]; }
+        else if (cstat) { c1 = stat(cst, cc); cs = stat(cst, Bl + cc); ct = stat(cst, 2 * Bl + cc); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rl = (lane >> 4) * 4 + q, row = i0 + rl;
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         if (lane == 0) unsafeAtomicAdd(a.scal + (dir ? SC_KL1 : SC_KL0), klacc);
     }
     if (a.c.w_hl != 0.f && z == 0 && wave == 0 && lane < 16 && i0 + lane < iend)
-        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(stat(rst, i0 - a.r0 + lane)) + 1.f);
+        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(grow ? grow[i0 + lane] : stat(rst, i0 - a.r0 + lane)) + 1.f);
     __syncthreads();
     // gradient rows: G[16, E] = dS_stripe[16, B] @ Y[B, E],  Y = normalised student embedding of the other modality
     // (this slice's columns only: the slices' partial rows are added in loss_finalize_kernel)
@@ -334,6 +343,15 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
             if (row < iend) G[(int64_t)(row - a.r0) * E + e0 + (lane & 15)] = acc[q];
         }
     }
+}
+
+// pass-A-only call of the row-block mode: the owned rows' statistics, slices added in order, for the caller's all-gather
+__global__ void loss_stats_out_kernel(LossArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 6 * a.Bl) return;
+    float v = 0.f;
+    for (int zz = 0; zz < a.zs; ++zz) v += a.stats[(int64_t)zz * 6 * a.Bl + i];
+    a.stats_out[i] = v;
 }
 
 // normalisation backward: x_hat = x / |x|  =>  dx = (g - x_hat (x_hat . g)) / |x| ; added to the tower-term gradient
@@ -413,7 +431,8 @@ namespace {
 
 int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B, int64_t E,
                      int64_t row0, int64_t rows, const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt,
-                     void* workspace, size_t ws_bytes, void* stream, const char* who) {
+                     void* workspace, size_t ws_bytes, void* stream, const char* who, const float* gathered_stats = nullptr,
+                     float* stats_out = nullptr) {
     DCLIP_REQUIRE(cfg && out_scalars && workspace, "%s: null argument", who);
     LossArgs a;
     a.c.w_l1 = cfg[0]; a.c.w_cos = cfg[1]; a.c.w_kl = cfg[2]; a.c.w_ce = cfg[3];
@@ -424,8 +443,9 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
     DCLIP_REQUIRE(B > 0 && E > 0 && E % 16 == 0 && E <= 1024, "%s: need E %% 16 == 0, E <= 1024 (E=%ld)", who, (long)E);
     DCLIP_REQUIRE(B <= 4096, "%s: B <= 4096 (stripe LDS budget), got %ld", who, (long)B);
     DCLIP_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= B, "%s: row block [%ld, %ld) outside [0, %ld)", who, (long)row0, (long)(row0 + rows), (long)B);
-    DCLIP_REQUIRE(rows == B || (a.c.w_hl == 0.f && a.c.w_sl == 0.f),
-                  "%s: hard_label / soft_label need the column statistics of every row: not available for a row block", who);
+    DCLIP_REQUIRE(rows == B || (a.c.w_hl == 0.f && a.c.w_sl == 0.f) || gathered_stats || stats_out,
+                  "%s: hard_label / soft_label need the statistics of every row: call once with stats_out, gather, call again with them", who);
+    a.gstats = gathered_stats; a.stats_out = stats_out;
     DCLIP_REQUIRE((a.c.w_kl == 0.f && a.c.w_sl == 0.f) || a.c.tau > 0.f, "%s: KL terms need temperature > 0", who);
     DCLIP_REQUIRE(ws_bytes >= dclip_distill_loss_workspace(B, E), "%s: workspace too small", who);
     DCLIP_REQUIRE(((uintptr_t)workspace % 256) == 0, "%s: workspace must be 256-byte aligned", who);
@@ -466,6 +486,10 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
     if (cross) {
         const dim3 grid((unsigned)((rows + 15) / 16), 2, (unsigned)a.zs);
         hipLaunchKernelGGL(loss_stripe_a_kernel, grid, dim3(256), 0, st, a);
+        if (stats_out && !gathered_stats) {      // pass A only: the caller gathers the statistics of all row blocks first
+            hipLaunchKernelGGL(loss_stats_out_kernel, dim3((unsigned)((6 * rows + 255) / 256)), dim3(256), 0, st, a);
+            return dclip_check_launch(who);
+        }
         const size_t lds = (size_t)16 * (((((B + 15) / 16) + a.zs - 1) / a.zs) * 16 + 4) * sizeof(float);
         DCLIP_REQUIRE(lds <= 160 * 1024, "%s: stripe does not fit LDS", who);
         hipLaunchKernelGGL(loss_stripe_b_kernel, grid, dim3(256), lds, st, a);
@@ -486,9 +510,10 @@ extern "C" int dclip_distill_loss(const float* s_img, const float* t_img, const 
 
 extern "C" int dclip_distill_loss_rows(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B,
                                        int64_t E, int64_t row0, int64_t rows, const float* cfg, float* out_scalars,
-                                       float* d_s_img, float* d_s_txt, void* workspace, size_t ws_bytes, void* stream) {
+                                       float* d_s_img, float* d_s_txt, const float* gathered_stats, float* stats_out,
+                                       void* workspace, size_t ws_bytes, void* stream) {
     return run_distill_loss(s_img, t_img, s_txt, t_txt, B, E, row0, rows, cfg, out_scalars, d_s_img, d_s_txt, workspace, ws_bytes,
-                            stream, "dclip_distill_loss_rows");
+                            stream, "dclip_distill_loss_rows", gathered_stats, stats_out);
 }
 
 // feature MSE (hidden_rep_mse / embedding_mse terms: hidden_mse.py:9-17, embed_mse.py:9-10):

@@ -31,17 +31,23 @@ class _FusedLossFn(torch.autograd.Function):
             from ..parallel import gather_embeddings
             B = s_img.shape[0]
             (gsi, gti, gst, gtt), rank, world = gather_embeddings([s_img, t_img, s_txt, t_txt])
+            import torch.distributed as dist
+            gstats = None
             if weights.get('hard_label', 0) or weights.get('soft_label', 0):
-                # the row / column softmax statistics of every row are needed: every rank evaluates the whole matrix
-                scal, d_i, d_t = ops.distill_loss(gsi, gti, gst, gtt, weights=weights, temperature=temperature)
-                d_i, d_t = d_i[rank * B:(rank + 1) * B], d_t[rank * B:(rank + 1) * B]
-            else:
-                # own row block [B, world * B] only (1 / world of the logits work); the 16 scalars are shares that add up
-                scal, d_i, d_t = ops.distill_loss(gsi, gti, gst, gtt, weights=weights, temperature=temperature,
-                                                  row0=rank * B, rows=B)
+                # the softmax statistics of every row (both directions) are needed: own rows first, then one small all-gather
+                st = ops.distill_loss(gsi, gti, gst, gtt, weights=weights, temperature=temperature, row0=rank * B, rows=B,
+                                      stats_only=True)
                 if world > 1:
-                    import torch.distributed as dist
-                    dist.all_reduce(scal, op=dist.ReduceOp.SUM)
+                    allst = torch.empty((world, 6, B), dtype=torch.float32, device=st.device)
+                    dist.all_gather_into_tensor(allst.view(-1), st.view(-1))
+                    gstats = allst.permute(1, 0, 2).reshape(6, world * B).contiguous()
+                else:
+                    gstats = st
+            # own row block [B, world * B] only (1 / world of the logits work); the 16 scalars are shares that add up
+            scal, d_i, d_t = ops.distill_loss(gsi, gti, gst, gtt, weights=weights, temperature=temperature,
+                                              row0=rank * B, rows=B, gathered_stats=gstats)
+            if world > 1:
+                dist.all_reduce(scal, op=dist.ReduceOp.SUM)
             d_i = d_i * float(world)
             d_t = d_t * float(world)
         else:

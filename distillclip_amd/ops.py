@@ -117,10 +117,13 @@ LOSS_SLOTS = {'out_l1': 0, 'out_cos': 1, 'out_kl': 2, 'out_ce': 3, 'cos_diff': 4
               'logits_mse': 7}
 
 
-def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=None, row0=None, rows=None):
+def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=None, row0=None, rows=None, gathered_stats=None,
+                 stats_only=False):
     """Fused loss fwd+bwd.  weights: {term: scale*percent}.  -> (scalars[16] device tensor, d_s_img, d_s_txt).
     row0 / rows: evaluate only the row block [row0, row0 + rows) of the (gathered) batch against all columns — gradients
-    [rows, E] of the owned samples, scalars = this block's share (sum over the blocks = the whole-batch values)."""
+    [rows, E] of the owned samples, scalars = this block's share (sum over the blocks = the whole-batch values).
+    hard_label / soft_label in row-block mode: first `stats_only=True` -> [6, rows] statistics of the owned rows; gather all
+    blocks into [6, B] and pass them as `gathered_stats` to the second call."""
     import ctypes
     _chk(s_img, t_img, s_txt, t_txt)
     B, E = s_img.shape
@@ -141,8 +144,14 @@ def distill_loss(s_img, t_img, s_txt=None, t_txt=None, *, weights, temperature=N
         lib().dclip_distill_loss(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, ctypes.cast(cfg_arr, ctypes.c_void_p),
                                  _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
     else:
+        stats = torch.empty((6, nrow), dtype=torch.float32, device=s_img.device) if stats_only else None
+        if gathered_stats is not None:
+            assert gathered_stats.shape == (6, B) and gathered_stats.dtype == torch.float32 and gathered_stats.is_contiguous()
         lib().dclip_distill_loss_rows(_p(s_img), _p(t_img), _p(s_txt), _p(t_txt), B, E, int(row0), nrow,
-                                      ctypes.cast(cfg_arr, ctypes.c_void_p), _p(out), _p(d_i), _p(d_t), _p(ws), ws_bytes, _stream())
+                                      ctypes.cast(cfg_arr, ctypes.c_void_p), _p(out), _p(d_i), _p(d_t), _p(gathered_stats),
+                                      _p(stats), _p(ws), ws_bytes, _stream())
+        if stats_only:
+            return stats
     return out, d_i, d_t
 
 

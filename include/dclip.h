@@ -233,12 +233,14 @@ int dclip_retrieval_metrics(const float* img, const float* txt, int64_t n, int64
  * [B, E] embeddings of all ranks, this call owns rows [row0, row0 + rows) — its own samples — against all B columns.
  * d_s_img / d_s_txt: [rows, E] gradients of the owned samples (d global loss / d embedding).  out_scalars: this block's share of
  * every scalar: summing the 16 values over the ranks (one small all-reduce) gives the loss of the concatenated batch.
- * Terms that need column statistics of every row (hard_label, soft_label) are rejected here: use dclip_distill_loss on the
- * gathered batch for those.  Same workspace query (with the gathered B).
+ * hard_label / soft_label need the softmax statistics of EVERY row (both directions): call once with stats_out (f32 [6, rows]; only the
+ * statistics pass runs, no gradients), all-gather the ranks' blocks into [6, B] (statistic-major, rows in rank order), and call again
+ * with gathered_stats.  Both pointers null: only terms without such statistics (cos_diff, logits_mse, tower terms) may be enabled.
+ * Same workspace query (with the gathered B).
  */
 int dclip_distill_loss_rows(const float* s_img, const float* t_img, const float* s_txt, const float* t_txt, int64_t B, int64_t E,
                             int64_t row0, int64_t rows, const float* cfg, float* out_scalars, float* d_s_img, float* d_s_txt,
-                            void* workspace, size_t ws_bytes, void* stream);
+                            const float* gathered_stats, float* stats_out, void* workspace, size_t ws_bytes, void* stream);
 /* feature MSE (hidden_rep_mse / embedding_mse: hidden_mse.py:9-17, embed_mse.py:9-10):
  *   loss_acc[0] += coef * mean((s - t)^2) ; ds_acc (nullable) += coef * 2 (s - t) / n */
 int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, float* loss_acc, float* ds_acc, void* stream);
