@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — image-text pairs/sec of one full distill step on N x MI355X (BASELINE.json metric).
+"""bench.py — distill-step throughput on N x MI355X (BASELINE.json metric: image-text pairs/sec of one full distill step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config lclip|image|text|lclip336]
 
-Workload (BASELINE.json configs[3], the config the pairs/sec metric is quoted on): l_clip.yaml dual distillation,
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N fresh rank processes (one per GPU, RCCL over
+xGMI) BEFORE it touches the GPU itself, relays rank 0's JSON line and exits non-zero if any rank fails.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are taken from the environment instead.
+
+Default workload (BASELINE.json configs[3], the config the pairs/sec metric is quoted on): l_clip.yaml dual distillation,
 224 px / 77 tokens, B = 512 pairs per GPU, frozen ViT-B/32 CLIP teacher (image + text towers), weight-shared students
 (RepeatVisionTransformer depth 6 / 24 heads / R=2, RepeatTextTransformer depth 4 / 12 heads / R=2), losses
 out_l1 + out_cos + 0.1 * cos_diff, fused AdamW.  One step = student fwd + teacher fwd + fused loss + student bwd +
-data-parallel gradient average (RCCL, N > 1) + optimizer step, on synthetic inputs already resident in HBM.
-Weak scaling: per-GPU batch fixed, local negatives like the reference's training_step.
+data-parallel exchange (N > 1: bucketed reduce-scatter under the backward -> sharded AdamW -> parameter all-gather) +
+optimizer step, on synthetic inputs already resident in HBM.  Weak scaling: per-GPU batch fixed, local negatives like the
+reference's training_step.  `--config` selects the other BASELINE configurations (image.yaml B=256,
+text.yaml B=1024, l_clip at 336 px B=512), each with its own unit and FLOP count.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -24,70 +29,225 @@ if ROOT not in sys.path:
 # one hardware queue per tower stream (+ main + RCCL): read at HIP initialisation, see distillclip_amd/__init__.py
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
-STEP_GFLOP_PER_PAIR = 42.17      # teacher fwd 14.86 + student fwd 9.10 + student bwd 18.20 GFLOP
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 S_IMG = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24, mlp_ratio=4.0,
-             qkv_bias=True, repeated_times=2, use_transform=True)            # l_clip.yaml:4-17
+             qkv_bias=True, repeated_times=2, use_transform=True)            # l_clip.yaml:4-17, image.yaml:5-23
 S_TXT = dict(depth=4, repeated_times=2, use_transform=True)                  # l_clip.yaml:18-23
-LOSS = dict(loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})     # l_clip.yaml:29-32
+S_TXT_C = dict(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)      # text.yaml:6-10
+LOSS_DUAL = dict(loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})     # l_clip.yaml:29-32
+LOSS_ONE = dict(loss_name=['out_l1', 'out_cos'])                                                # image.yaml:25-26, text.yaml:12-13
+
+# step FLOP per unit: SURVEY.md §8d (teacher fwd + student fwd + student bwd = 2 x fwd)
+WORKLOADS = {
+    'lclip': dict(kind='dual', res=224, batch=512, unit='pairs', gflop=42.17,
+                  metric='image-text pairs/sec (distill step)',
+                  desc='l_clip.yaml dual distill: ViT-B/32 CLIP teacher -> weight-shared ViT(6x768,24h,R2) + text(4x768,12h,R2) '
+                       'students, 224px/77tok, losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW'),
+    'lclip336': dict(kind='dual', res=336, batch=512, unit='pairs', gflop=65.98,
+                     metric='image-text pairs/sec (distill step, 336 px)',
+                     desc='l_clip.yaml dual distill at 336x336 (101 image tokens; BASELINE configs[4] per-GPU share): same towers, '
+                          'losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW'),
+    'image': dict(kind='image', res=224, batch=256, unit='images', gflop=22.65,
+                  metric='images/sec (image.yaml distill step)',
+                  desc='image.yaml: ViT-B/32 image teacher -> weight-shared ViT(6x768,24h,R2) student, freeze_embed, losses '
+                       'out_l1+out_cos, fwd+loss+bwd+AdamW'),
+    'text': dict(kind='text', res=224, batch=1024, unit='captions', gflop=19.61,
+                 metric='captions/sec (text.yaml distill step)',
+                 desc='text.yaml: CLIP text teacher (12x512, causal) -> weight-shared text(4x768,12h,R2, compressed embedding) '
+                      'student, 77 tok, losses out_l1+out_cos, fwd+loss+bwd+AdamW'),
+}
 
 
 def T(d):
+    import numpy as np
+    import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
 
 
-def build_model(seed, device):
+def build_model(wl, seed, device):
     from distillclip_amd import synth
-    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model import DualDistillModel, DistillModel
     from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
-    s_img, s_txt = RepeatVisionTransformer(**S_IMG), RepeatTextTransformer(**S_TXT)
-    s_img.load_state_dict(T(synth.student_image_state(seed, **S_IMG)))
-    s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT)))
-    tsd = synth.teacher_image_state(seed)
+    tsd = synth.teacher_image_state(seed, resolution=wl['res'])
     tsd.update(synth.teacher_text_state(seed))
-    model = DualDistillModel(s_img, s_txt, LOSS, warm_steps=15, total_steps=300, weight_decay=1e-3, lr=1e-4,
-                             download_root='./.cache', teacher_state_dict=T(tsd))       # l_clip.yaml:35-39
+    tsd = T(tsd)
+    if wl['kind'] == 'dual':
+        cfg_i = dict(S_IMG, img_size=wl['res'])
+        s_img, s_txt = RepeatVisionTransformer(**cfg_i), RepeatTextTransformer(**S_TXT)
+        s_img.load_state_dict(T(synth.student_image_state(seed, **cfg_i)))
+        s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT)))
+        model = DualDistillModel(s_img, s_txt, LOSS_DUAL, warm_steps=15, total_steps=300, weight_decay=1e-3, lr=1e-4,
+                                 download_root='./.cache', teacher_state_dict=tsd)       # l_clip.yaml:35-39
+    elif wl['kind'] == 'image':
+        s_img = RepeatVisionTransformer(**S_IMG)
+        s_img.load_state_dict(T(synth.student_image_state(seed, **S_IMG)))
+        model = DistillModel(s_img, LOSS_ONE, './.cache', freeze_embed=True, teacher_need_layers=[0, 1, 10, 11],
+                             model_type='image', warm_steps=10, total_steps=200, weight_decay=1e-2, lr=5e-3,
+                             teacher_state_dict=tsd)                                     # image.yaml:24-35
+    else:
+        s_txt = RepeatTextTransformer(**S_TXT_C)
+        s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT_C)))
+        model = DistillModel(s_txt, LOSS_ONE, './.cache', teacher_need_layers=[0, 1, 10, 11], model_type='text',
+                             warm_steps=10, total_steps=200, weight_decay=1e-2, lr=5e-3,
+                             teacher_state_dict=tsd)                                     # text.yaml:11-21
     return model.to(device)
 
 
-def cpu_baseline(seed, target_seconds=20.0):
-    """The oracle (CPU fp32 restatement of the reference) timed on this host: same model, same step contents
-    (fwd, loss, backward, AdamW), bounded sample."""
+def make_inputs(wl, seed, B):
+    import torch
+    from distillclip_amd import synth
+    image = torch.from_numpy(synth.images(seed, B, wl['res'])) if wl['kind'] != 'text' else None
+    caps = synth.captions(seed, B) if wl['kind'] != 'image' else None
+    text = torch.from_numpy(caps) if caps is not None else None
+    return image, text, caps
+
+
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(wl, seed, budget_s=40.0):
+    """The oracle (CPU fp32 restatement of the reference, pinned by reference-run goldens) timed on this host: same model, same
+    step contents (fwd, loss, zero_grad, backward, AdamW).  BASELINE.md §2: B in {4, 32}, thread sweep, 1 warm-up then best of
+    >= 3 steps; bounded to ~budget_s of CPU work (configurations are tried most-promising first and the sweep stops when the
+    budget is spent).  Reports the best (batch, threads)."""
+    import torch
     import oracle
     from distillclip_amd import synth
-    nthreads = torch.get_num_threads()
-    B = 8
-    sd_i = {k: v.requires_grad_(True) for k, v in T(synth.student_image_state(seed, **S_IMG)).items()}
-    sd_t = {k: v.requires_grad_(True) for k, v in T(synth.student_text_state(seed, **S_TXT)).items()}
-    t_i, t_t = T(synth.teacher_image_state(seed)), T(synth.teacher_text_state(seed))
-    image = torch.from_numpy(synth.images(seed, B))
-    text = torch.from_numpy(synth.captions(seed, B))
-    opt = torch.optim.AdamW(list(sd_i.values()) + list(sd_t.values()), lr=1e-4, weight_decay=1e-3)
-    lc = oracle.LossOracle(LOSS['loss_name'], LOSS['loss_scale'])
+    ncpu = os.cpu_count() or 1
+    kind = wl['kind']
+    res = wl['res']
+    cfg_i = dict(S_IMG, img_size=res)
+    sd_i = sd_t = None
+    params = []
+    tsd_i = T(synth.teacher_image_state(seed, resolution=res)) if kind != 'text' else None
+    tsd_t = T(synth.teacher_text_state(seed)) if kind != 'image' else None
+    if kind != 'text':
+        sd_i = {k: v.requires_grad_(True) for k, v in T(synth.student_image_state(seed, **cfg_i)).items()}
+        if kind == 'image':      # freeze_embed (distil_model.py:197-213): teacher patch / class / positional embeddings, frozen
+            sd_i['patch_embed.proj.weight'] = tsd_i['visual.conv1.weight'].clone()
+            sd_i['cls_token'] = tsd_i['visual.class_embedding'].view(1, 1, -1).clone()
+            sd_i['pos_embed'] = tsd_i['visual.positional_embedding'].unsqueeze(0).clone()
+        params += [v for v in sd_i.values() if v.requires_grad]
+    if kind != 'image':
+        tcfg = S_TXT if kind == 'dual' else S_TXT_C
+        sd_t = {k: v.requires_grad_(True) for k, v in T(synth.student_text_state(seed, **tcfg)).items()}
+        params += list(sd_t.values())
+    lr, wd = (1e-4, 1e-3) if kind == 'dual' else (5e-3, 1e-2)
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    lc = oracle.LossOracle(**(LOSS_DUAL if kind == 'dual' else LOSS_ONE))
 
-    def step():
-        so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, 24), oracle.student_text_forward(sd_t, text, 12))
-        with torch.no_grad():
-            to = oracle.clip_forward(oracle.teacher_image_forward(t_i, image), oracle.teacher_text_forward(t_t, text))
-        loss, _ = lc(so, to, 'all')
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-    step()                                  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_seconds or n >= 16:
+    def make_step(B):
+        image, text, _ = make_inputs(wl, seed, B)
+
+        def step():
+            if kind == 'dual':
+                so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, 24), oracle.student_text_forward(sd_t, text, 12))
+                with torch.no_grad():
+                    to = oracle.clip_forward(oracle.teacher_image_forward(tsd_i, image), oracle.teacher_text_forward(tsd_t, text))
+                loss, _ = lc(so, to, 'all')
+            elif kind == 'image':
+                so = oracle.student_image_forward(sd_i, image, 24)
+                with torch.no_grad():
+                    to = oracle.teacher_image_forward(tsd_i, image)
+                loss, _ = lc(so, to, 'image')
+            else:
+                so = oracle.student_text_forward(sd_t, text, 12)
+                with torch.no_grad():
+                    to = oracle.teacher_text_forward(tsd_t, text)
+                loss, _ = lc(so, to, 'text')
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        return step
+
+    threads = sorted({max(1, ncpu // 4), max(1, ncpu // 2), ncpu}, reverse=True)
+    plan = [(32, t) for t in threads] + [(4, t) for t in reversed(threads)]
+    t_start = time.perf_counter()
+    tried, best = [], None
+    for B, nt in plan:
+        if tried and time.perf_counter() - t_start > budget_s:
             break
-    return {'value': round(n * B / dt, 3), 'unit': 'pairs/s', 'cores': nthreads, 'kind': 'port',
-            'sample': f'{n} steps of the same l_clip dual step at batch {B} (fp32, torch CPU, {nthreads} threads)'}
+        torch.set_num_threads(nt)
+        step = make_step(B)
+        step()                                      # warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 2.0 * budget_s:
+                break
+        rate = B / min(times)
+        tried.append({'batch': B, 'threads': nt, 'best_step_s': round(min(times), 4), 'steps_timed': len(times),
+                      f'{wl["unit"]}_per_s': round(rate, 3)})
+        if best is None or rate > best[0]:
+            best = (rate, B, nt, len(times))
+    torch.set_num_threads(ncpu)
+    rate, B, nt, n = best
+    return {'value': round(rate, 3), 'unit': f'{wl["unit"]}/s', 'cores': nt, 'kind': 'port', 'cpu_model': cpu_model_name(),
+            'host_logical_cpus': ncpu,
+            'sample': f'best of {n} timed steps (after 1 warm-up) of the same {wl["kind"]} distill step at batch {B}, fp32 torch CPU, '
+                      f'{nt} threads; sweep over batch {{32, 4}} x threads {threads} bounded to ~{int(budget_s)} s',
+            'sweep': tried}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, started before this process makes any GPU call
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # rank 0 inherits stdout (its JSON line is this command's output); the other ranks' stdout goes to stderr
+        out = None if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                 # a rank failed: the others would wait in a collective forever
+                    q.terminate()
+    if rc == 0 and any(p.returncode != 0 for p in procs):
+        rc = 1
+    return rc
+
+
+def dry_launch():
+    """launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 reports the world size the ranks observed"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({'dry_launch': True, 'n_gpus': int(t.item()), 'backend': 'gloo'}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -95,9 +255,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=512, help='pairs per GPU (BASELINE.json configs[3])')
+    ap.add_argument('--config', choices=sorted(WORKLOADS), default='lclip',
+                    help='lclip = BASELINE.json configs[3] (the headline metric); image / text / lclip336 = configs[1] / [2] / [4]')
+    ap.add_argument('--batch', type=int, default=0, help='units per GPU (default: the configuration\'s own batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dry-launch', action='store_true', help='spawn the ranks, join a gloo group on the CPU, exit (launcher test)')
     ap.add_argument('--global-negatives', action='store_true',
                     help='opt-in north-star mode: in-batch negatives over all ranks (all-gather of the embeddings over RCCL)')
     ap.add_argument('--teacher-text-prefix', action='store_true',
@@ -105,11 +268,18 @@ def main():
                          'less work; NOT used for the headline number, which processes all 77 positions)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # nothing above touched the GPU (torch is not even imported)
+    if args.dry_launch:
+        return dry_launch()
+
+    import torch
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -119,45 +289,50 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        world = dist.get_world_size()                       # n_gpus reported = the RCCL world size the ranks observed
 
-    from distillclip_amd import synth
     from distillclip_amd._lib import lib
+    wl = WORKLOADS[args.config]
+    dual = wl['kind'] == 'dual'
     seed = 2022                                             # main.py:24 seed_everything_default
-    model = build_model(seed, device)
-    (opt,), _ = model.configure_optimizers()
-    model.loss_control.global_negatives = args.global_negatives
+    model = build_model(wl, seed, device)
     if use_dist:
         from distillclip_amd.parallel import GradSync
         model._sync = GradSync()
         model._sync.enabled = True          # also at world size 1 (DCLIP_FORCE_DIST): the collectives still run
-    B = args.batch
-    image = torch.from_numpy(synth.images(seed + rank, B)).to(device)      # per-rank shard, resident in HBM
-    caps = synth.captions(seed + rank, B)
-    text = torch.from_numpy(caps).to(device)
-    # the tokenizer knows caption lengths on the host: the causal teacher text tower only needs the prefix holding every EOT
-    tt_tokens = int((caps != 0).sum(1).max()) if args.teacher_text_prefix else 77
-    model.set_text_length_hint(tt_tokens if args.teacher_text_prefix else None)
+    (opt,), _ = model.configure_optimizers()
+    model.loss_control.global_negatives = args.global_negatives
+    B = args.batch or wl['batch']
+    image, text, caps = make_inputs(wl, seed + rank, B)     # per-rank shard, resident in HBM
+    image = image.to(device) if image is not None else None
+    text = text.to(device) if text is not None else None
+    batch = [image, text] if dual else (image if wl['kind'] == 'image' else text)
+    tt_tokens = 77
+    if dual:
+        # the tokenizer knows caption lengths on the host: the causal teacher text tower only needs the prefix holding every EOT
+        tt_tokens = int((caps != 0).sum(1).max()) if args.teacher_text_prefix else 77
+        model.set_text_length_hint(tt_tokens if args.teacher_text_prefix else None)
 
     FUSED_ZERO = os.environ.get('DCLIP_BENCH_FUSED_ZERO', '1') != '0'
     OVERLAP_OPT = os.environ.get('DCLIP_BENCH_OVERLAP_OPT', '1') != '0'   # per-tower optimizer step on the tower's own stream
-
-    PIPE_TEACHER = os.environ.get('DCLIP_BENCH_PIPELINE_TEACHER', '0') == '1'
+    PIPE_TEACHER = dual and os.environ.get('DCLIP_BENCH_PIPELINE_TEACHER', '0') == '1'
     pending = {'teacher': None}
 
     def step():
         if PIPE_TEACHER:
             # the frozen teacher of the NEXT batch runs under this batch's student backward (same work per step, same values)
-            handle = pending['teacher'] or model.teacher_forward_async([image, text])
-            loss = model.training_step([image, text], teacher=handle)
+            handle = pending['teacher'] or model.teacher_forward_async(batch)
+            loss = model.training_step(batch, teacher=handle)
             opt.zero_grad()
             loss.backward()
-            pending['teacher'] = model.teacher_forward_async([image, text])
+            pending['teacher'] = model.teacher_forward_async(batch)
             model.backward_and_sync(None, defer_wait=OVERLAP_OPT)
         else:
-            loss = model.training_step([image, text])
+            loss = model.training_step(batch)
             opt.zero_grad()
             model.backward_and_sync(loss, defer_wait=OVERLAP_OPT)
-        opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT, join=not OVERLAP_OPT)   # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
+        # the fused kernel clears each gradient element as it consumes it: the next zero_grad() is free
+        opt.step(zero_grad=FUSED_ZERO, overlap=OVERLAP_OPT, join=not OVERLAP_OPT)
         return loss
 
     def barrier():
@@ -187,7 +362,9 @@ def main():
         import ctypes
         cap = 20000
         nprobe = 2
-        multi, model.multi_stream = model.multi_stream, False      # one stream: event intervals then bracket one kernel each
+        multi = getattr(model, 'multi_stream', None)
+        if multi is not None:
+            model.multi_stream = False          # one stream: event intervals then bracket one kernel each
         step()
         torch.cuda.synchronize()
         if rank == 0:
@@ -195,7 +372,8 @@ def main():
         for _ in range(nprobe):
             step()
         torch.cuda.synchronize()
-        model.multi_stream = multi
+        if multi is not None:
+            model.multi_stream = multi
     if rank == 0 and not args.no_roofline:
         kind = (ctypes.c_int32 * cap)()
         ms = (ctypes.c_float * cap)()
@@ -208,41 +386,50 @@ def main():
         for i in range(n):
             a = agg.setdefault(kind[i], [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += ms[i]; a[2] += fl[i]; a[3] += by[i]
-        names = {0: 'gemm_nt_kernel', 1: 'gemm_tn_kernel', 2: 'ln_fwd_kernel', 3: 'distill_loss'}
+        names = {0: 'gemm_nt_kernel', 1: 'gemm_tn_kernel', 2: 'ln_fwd_kernel', 3: 'distill_loss', 4: 'attention', 5: 'ln_bwd_kernel'}
         g = agg.get(0, [1, 1.0, 0.0, 0.0])
         achieved = g[2] / (g[1] * 1e-3) / 1e12
-        traffic = None                                          # HBM bytes / launch from the committed PMC passes of this command
+        # HBM bytes / launch: from the committed rocprofv3 PMC passes of this same command (separate --pmc runs, FETCH_SIZE x 2 +
+        # WRITE_SIZE as MI355X_MICROARCH.md prescribes) — counters cannot be read from inside the process
+        traffic, traffic_source = None, None
         import glob
-        tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+        tag = '' if args.config == 'lclip' else f'{args.config}_'
+        tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{tag}traffic.json')))
         if tj:
             traffic = json.load(open(tj[-1])).get('gemm_nt', {}).get('hbm_bytes_per_launch')
+            traffic_source = f'profiles/{os.path.basename(tj[-1])} (committed rocprofv3 --pmc passes of this command; not measured in this run)'
         roofline = {'kernel': 'gemm_nt (gemm_nt_kernel 128x128 + gemm_nt256_kernel 256x256)', 'bound': 'mfma',
                     'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_source': traffic_source,
                     'algorithmic_bytes_per_launch': g[3] / g[0],
                     'launches_per_step': g[0] // nprobe, 'avg_launch_us': round(g[1] / g[0] * 1e3, 2),
                     'flop_per_launch': g[2] / g[0],
                     'others': {names.get(k, str(k)): {'launches_per_step': v[0] // nprobe, 'ms_per_step': round(v[1] / nprobe, 3),
                                                       'TFLOP/s': round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
-                                                      'GB/s': round(v[3] / (v[1] * 1e-3) / 1e9, 1)} for k, v in agg.items()}}
+                                                      'GB/s': round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                                      'hbm_frac': round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                               for k, v in agg.items()}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(seed)
+        cpu = cpu_baseline(wl, seed)
 
     if rank == 0:
-        pairs = B * world * args.steps
-        value = pairs / dt
+        units = B * world * args.steps
+        value = units / dt
+        dp = 'none'
+        if use_dist:
+            dp = 'reduce-scatter -> sharded AdamW -> all-gather' if getattr(model._sync, 'sharded', False) else 'all-reduce'
         out = {
-            'metric': 'image-text pairs/sec (distill step)', 'value': round(value, 2), 'unit': 'pairs/s',
+            'metric': wl['metric'], 'value': round(value, 2), 'unit': f'{wl["unit"]}/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'l_clip.yaml dual distill: ViT-B/32 CLIP teacher -> weight-shared ViT(6x768,24h,R2) + '
-                                   'text(4x768,12h,R2) students, 224px/77tok, losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW',
-                       'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}',
-                       'negatives': 'global (all-gather over RCCL)' if args.global_negatives else 'local (reference training_step semantics)', 'optimizer_in_step': True,
-                       'teacher_text_tokens_processed': tt_tokens},
-            'step_gflop_per_pair': STEP_GFLOP_PER_PAIR,
-            'mfma_roofline_frac_whole_step': round(value / world * STEP_GFLOP_PER_PAIR * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            'config': {'workload': wl['desc'], 'name': args.config,
+                       'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}', 'gradient_exchange': dp,
+                       'negatives': 'global (all-gather over RCCL)' if args.global_negatives else 'local (reference training_step semantics)',
+                       'optimizer_in_step': True, 'teacher_text_tokens_processed': tt_tokens},
+            f'step_gflop_per_{wl["unit"][:-1]}': wl['gflop'],
+            'mfma_roofline_frac_whole_step': round(value / world * wl['gflop'] * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             'final_loss': round(final_loss, 6),
         }
         if roofline is not None:

@@ -13,7 +13,7 @@ _HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'dclip.h')
 _CT = {
     "int32_t": ctypes.c_int32,
     'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
-    'double': ctypes.c_double,
+    'double': ctypes.c_double, 'dclip_bucket_cb': ctypes.c_void_p,
 }
 
 
@@ -63,7 +63,7 @@ class _Lib:
 
     def __getattr__(self, name):
         fn = getattr(self._dll, name)
-        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name == 'dclip_version' or name.endswith('_supported'):
+        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name in ('dclip_version', 'dclip_encoder_num_grad_buckets') or name.endswith('_supported'):
             return fn
 
         def call(*args):

@@ -5,11 +5,16 @@ The reference trains under Lightning, whose `ModelCheckpoint` writes `{'state_di
 'hyper_parameters'}`; stage 2 (`l_clip.yaml` load_path) reads the stage-1 files back through `load_weight`
 (reference model/dual_distill_model.py:22-38: keep `student.*`, strip the prefix).  `save_checkpoint` writes that layout from
 the mirror modules (whose parameter names equal the reference's), `load_checkpoint` restores model + fused optimizer +
-schedule, so a file written here feeds the reference's `load_weight` and vice versa.
+schedule.  Guarantee: the weights (`state_dict`, both directions, incl. the reference's `load_weight`) and the optimizer state
+(`optimizer_states[0]` loads into `torch.optim.AdamW` and back).  `pytorch-lightning_version` carries a parseable 1.x version
+(the reference does not pin Lightning; `pytorch_lightning.cli` + `find_usable_cuda_devices` + `validation_epoch_end` +
+`save_config_overwrite` bound it to 1.8-1.9) so Lightning's checkpoint migration can compare it; the writer's own tag lives
+under `distillclip_amd_format`.  `lr_schedulers[0]` carries the keys a `LambdaLR.load_state_dict` expects.
 """
 import torch
 
-FORMAT = 'distillclip_amd/lightning-layout-1'
+FORMAT = 'distillclip_amd/lightning-layout-2'
+LIGHTNING_VERSION = '1.9.5'
 
 
 def _plain(v):
@@ -30,7 +35,8 @@ def trainable_parameters(model):
 def checkpoint_dict(model, optimizer=None, scheduler=None, epoch=0, global_step=0):
     if optimizer is not None and hasattr(optimizer, 'join'):
         optimizer.join()                         # un-joined per-tower updates must land before the weights are copied
-    ckpt = {'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': FORMAT,
+    ckpt = {'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': LIGHTNING_VERSION,
+            'distillclip_amd_format': FORMAT,
             'state_dict': {k: v.detach().to('cpu', copy=True) for k, v in model.state_dict().items()},
             'hyper_parameters': _plain(dict(getattr(model, 'hparams', {})))}
     if optimizer is not None:

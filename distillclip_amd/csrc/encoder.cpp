@@ -403,9 +403,31 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
     return DCLIP_OK;
 }
 
+// All-token output of the final norm + projection (reference _common.py:210-215, text_encoder.py:69-72,
+// weight_share_model.py:363-366 / :503-506: `last_layer_output`, of which `last_representation` is one row per sample).  The
+// training path projects only the picked row; this call produces the whole [B*N, E] tensor on request from the residual
+// stream the most recent forward of this tower left in `workspace`.
+extern "C" int dclip_encoder_last_layer_output(const dclip_encoder* e, int64_t B, const void* const* params, const void* wcache,
+                                               void* workspace, size_t ws_bytes, int training, void* scratch, float* out, void* st) {
+    DCLIP_REQUIRE(e && params && wcache && workspace && scratch && out, "dclip_encoder_last_layer_output: null argument");
+    DCLIP_REQUIRE(B > 0, "dclip_encoder_last_layer_output: empty batch");
+    const Plan& p = e->p;
+    DCLIP_REQUIRE(!training || p.student, "dclip_encoder_last_layer_output: the teacher tower is inference-only");
+    Work w;
+    layout(p, B, training != 0, workspace, w);
+    DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_last_layer_output: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    const bf16_t* W = (const bf16_t*)wcache;
+    const int64_t M = B * p.N, D = p.D, E = p.E;
+    const int nex = p.L * p.R, f = p.p_final;
+    CK(dclip_layernorm_fwd(w.X[nex], D, nullptr, PF(params, f), PF(params, f + 1), scratch, D, 0, nullptr, nullptr, M, D, 1e-5f, st));
+    CK(gemm(scratch, D, W + p.w_head, D, out, E, M, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
+    return DCLIP_OK;
+}
+
 extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
                                       void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
-                                      const float* d_last_representation, const float* const* d_rep, const float* d_emb, void* st) {
+                                      const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                                      dclip_bucket_cb on_bucket, void* cb_user, void* st) {
     DCLIP_REQUIRE(e && input && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
     const Plan& p = e->p;
     DCLIP_REQUIRE(p.student, "dclip_encoder_backward: only the student tower trains");
@@ -436,6 +458,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     if (hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
     CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
                            GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
+    // gradient bucket 0 (final norm + head) is complete: every launch that writes it is enqueued on `st`
+    if (on_bucket) on_bucket(cb_user, 0);
 
     // ---- blocks, last execution first --------------------------------------------------------------------------
     for (int ei = nex - 1; ei >= 0; --ei) {
@@ -479,6 +503,9 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         bf16_t* gb_next = ei > 0 ? w.gb_f2 + (int64_t)((ei - 1) % R) * M * D : w.Gb;
         CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(sr.n1w), GR(sr.n1b),
                                ei > 0 ? GR(sblock(p, (ei - 1) / p.R).f2b) : nullptr, M, D, st));
+        // block l's gradients (shared weights: both repeats; its fc2 bias also collects from block l + 1's first LayerNorm
+        // backward, which ran earlier) are complete after its first execution's backward: bucket 1 + (L - 1 - l)
+        if (r == 0 && on_bucket) on_bucket(cb_user, 1 + (p.L - 1 - l));
     }
 
     // ---- embedding ---------------------------------------------------------------------------------------------
@@ -508,5 +535,21 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
             CK(dclip_token_table_bwd(w.tok_sum, GR(1), nullptr, nullptr, N, D, 0, st));
         }
     }
+    if (on_bucket) on_bucket(cb_user, p.L + 1);          // embedding parameters: the last bucket
+    return DCLIP_OK;
+}
+
+// Gradient buckets in the order the backward completes them (data-parallel exchange, SURVEY.md section 8e Collective 1):
+// bucket 0 = final norm + head, 1 .. L = blocks L-1 .. 0, L + 1 = embedding parameters.  Each is a contiguous range of the
+// canonical parameter order, hence a contiguous range of a flat gradient buffer laid out in that order.
+extern "C" int32_t dclip_encoder_num_grad_buckets(const dclip_encoder* e) { return e ? e->p.L + 2 : -1; }
+extern "C" int dclip_encoder_grad_bucket(const dclip_encoder* e, int32_t bucket, int32_t* first_param, int32_t* end_param) {
+    DCLIP_REQUIRE(e && first_param && end_param, "dclip_encoder_grad_bucket: null argument");
+    const Plan& p = e->p;
+    DCLIP_REQUIRE(bucket >= 0 && bucket <= p.L + 1, "dclip_encoder_grad_bucket: bucket %d out of range 0..%d", bucket, p.L + 1);
+    const int per_block = p.student ? P_PER_SBLOCK + p.R * P_PER_SREPEAT : P_PER_TBLOCK;
+    if (bucket == 0) { *first_param = p.p_final; *end_param = p.n_params; }
+    else if (bucket == p.L + 1) { *first_param = 0; *end_param = p.p_blocks; }
+    else { const int l = p.L - bucket; *first_param = p.p_blocks + l * per_block; *end_param = *first_param + per_block; }
     return DCLIP_OK;
 }

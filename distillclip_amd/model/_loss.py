@@ -28,8 +28,14 @@ class _FusedLossFn(torch.autograd.Function):
         two = s_txt is not None
         if global_negatives and two:
             # opt-in north-star mode: in-batch negatives over the GLOBAL batch (all ranks), one fused all-gather over RCCL
-            from ..parallel import gather_embeddings
+            from ..parallel import gather_embeddings, check_equal_batch, world_size
             B = s_img.shape[0]
+            # rows are addressed as rank * B and the fused kernel holds at most 4096 gathered rows: fail on EVERY rank, before
+            # the first collective, rather than desynchronise it (ragged last batch) or fail on one rank (kernel limit)
+            check_equal_batch(B, s_img.device)
+            if world_size() * B > 4096:
+                raise ValueError(f'global negatives: world * batch = {world_size() * B} exceeds the fused loss kernel\'s 4096 '
+                                 f'gathered rows (include/dclip.h: dclip_distill_loss_rows)')
             (gsi, gti, gst, gtt), rank, world = gather_embeddings([s_img, t_img, s_txt, t_txt])
             import torch.distributed as dist
             gstats = None

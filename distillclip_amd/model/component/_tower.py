@@ -16,6 +16,9 @@ class EncoderCfg(ctypes.Structure):
         'in_chans', 'vocab', 'embed_rank', 'head_mix', 'causal')]
 
 
+_BUCKET_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)      # include/dclip.h: dclip_bucket_cb
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -47,6 +50,10 @@ class HipTower:
         self.bwd_stream = None
         self.grads_ready = None
         self.opt_done = None                       # event of an un-joined FusedAdamW.step(overlap=True, join=False)
+        self.sync = None                           # parallel.GradSync of a data-parallel run (set by the model)
+        self.dp = None                             # parallel._Shards: bucket / shard plan of this tower's flat buffers
+        self.gshard = None                         # this rank's averaged gradient shards (reduce-scatter output)
+        self.dp_released = 0
         # trainable towers re-cast their bf16 weight cache at every forward unless an optimizer that maintains
         # `wcache_dirty` itself (FusedAdamW) has taken over; any other in-place update of the masters needs the re-cast
         self._prepare_always = True
@@ -116,6 +123,41 @@ class HipTower:
         wbytes = lib().dclip_encoder_wcache_bytes(self._handle)
         self.wcache = torch.empty(wbytes, dtype=torch.uint8, device=device)
         self.wcache_dirty = True
+
+    def param_offsets(self):
+        """flat element offset of every canonical parameter index (absent parameters take the next live one's), + total"""
+        ps = self._params()
+        offs, off = [], 0
+        for p in ps:
+            offs.append(off)
+            if p is not None:
+                off += (p.numel() + 63) // 64 * 64
+        offs.append(off)
+        return offs
+
+    def grad_buckets(self):
+        """[(begin, end)] flat ranges in the order the backward completes them (include/dclip.h: dclip_encoder_grad_bucket)"""
+        offs = self.param_offsets()
+        first, end = ctypes.c_int32(), ctypes.c_int32()
+        out = []
+        for i in range(lib().dclip_encoder_num_grad_buckets(self._handle)):
+            lib().dclip_encoder_grad_bucket(self._handle, i, ctypes.byref(first), ctypes.byref(end))
+            out.append((offs[first.value], offs[end.value]))
+        return out
+
+    def trainable_ranges(self):
+        """contiguous [begin, end) element ranges of the requires_grad parameters inside the flat buffers"""
+        live = [p for p in self._params() if p is not None]
+        out = []
+        for p, off in zip(live, self._offsets):
+            if not p.requires_grad:
+                continue
+            end = off + (p.numel() + 63) // 64 * 64
+            if out and out[-1][1] == off:
+                out[-1][1] = end
+            else:
+                out.append([off, end])
+        return out
 
     def attach_grads(self):
         """Make p.grad views of the flat gradient buffer.  If any trainable p.grad was dropped (zero_grad(set_to_none)),
@@ -188,7 +230,28 @@ class HipTower:
                                     out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(), int(tokens_eff),
                                     torch.cuda.current_stream().cuda_stream)
         self._saved_batch = B if training else None
+        self._last_fwd = (B, bool(training), int(tokens_eff))
         return out, x, reps, emb
+
+    @torch.no_grad()
+    def last_layer_output(self):
+        """[B, N, E] f32: final norm + projection of EVERY token of the most recent forward (reference `last_layer_output`,
+        output.py:16-35).  Computed on request from the residual stream still resident in the workspace; not part of the autograd
+        graph (no loss term on the hot path consumes it)."""
+        last = getattr(self, '_last_fwd', None)
+        if last is None:
+            raise RuntimeError('last_layer_output: run a forward first')
+        B, training, tokens_eff = last
+        if tokens_eff:
+            raise RuntimeError('last_layer_output is not available when the text teacher ran on a caption prefix (max_tokens hint)')
+        N, D, E = self.cfg.tokens, self.cfg.width, self.cfg.out_dim
+        dev = self.workspace.device
+        scratch = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev)
+        out = torch.empty((B, N, E), dtype=torch.float32, device=dev)
+        lib().dclip_encoder_last_layer_output(self._handle, B, _ptr_array(self._params()), self.wcache.data_ptr(),
+                                              self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
+                                              scratch.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
 
     def backward(self, x, d_out, d_reps=None, d_emb=None):
         B = x.shape[0]
@@ -204,10 +267,25 @@ class HipTower:
         d_out = d_out.contiguous().float()
         keep = [None if g is None else g.contiguous().float() for g in (d_reps or [])]
         d_emb = None if d_emb is None else d_emb.contiguous().float()
+        # data-parallel run: every gradient bucket is handed to the exchange as soon as its last writer is enqueued, so the
+        # reduce-scatter of block l travels under the backward GEMMs of block l - 1
+        cb, failed = None, []
+        if self.dp is not None and self.sync is not None and self.sync.enabled:
+            def _ready(_user, bucket):
+                try:
+                    self.sync.bucket_ready(self, bucket)
+                except BaseException as exc:       # an exception cannot cross the C frame: re-raised below
+                    failed.append(exc)
+            cb = _BUCKET_CB(_ready)
+            self.dp_released = 0
         lib().dclip_encoder_backward(self._handle, x.data_ptr(), B, _ptr_array(ps), _ptr_array(gs), self.wcache.data_ptr(),
                                      self.workspace.data_ptr(), self.workspace.numel(), d_out.data_ptr(),
                                      _ptr_array(keep) if any(g is not None for g in keep) else None,
-                                     None if d_emb is None else d_emb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                     None if d_emb is None else d_emb.data_ptr(),
+                                     ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None,
+                                     torch.cuda.current_stream().cuda_stream)
+        if failed:
+            raise failed[0]
         self._saved_batch = None
         # gradient exchange may start as soon as THIS tower's backward is done (GradSync waits on this event, not on the
         # whole backward pass): the image tower's all-reduce overlaps the (longer) text tower backward

@@ -121,7 +121,12 @@ class ImageEncoder(nn.Module):
         with torch.no_grad():   # hidden states only for `need_layers` (reference _common.py:154-158)
             out, _, reps, emb = self._tower.forward(image, training=False, need_rep=co.need_rep, need_emb=co.need_emb,
                                                     rep_layers=list(self.need_layers) if self.need_layers is not None else None)
-        return VisionTransformerOutput(last_representation=out, representations=reps, embedding=emb)
+        llo = self._tower.last_layer_output() if getattr(co, 'need_last_layer_output', False) else None
+        return VisionTransformerOutput(last_representation=out, last_layer_output=llo, representations=reps, embedding=emb)
+
+    def last_layer_output(self):
+        """[B, N, E] = ln_post(x) @ proj for every token of the most recent forward (reference _common.py:210-215)"""
+        return self._tower.last_layer_output()
 
     def forward(self, image, control_output: ControlOutput = None):
         return self.encode_image(image, control_output)

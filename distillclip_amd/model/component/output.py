@@ -14,12 +14,17 @@ class ControlOutput:
     need_value_map: bool = False
     need_attn_prob: bool = False
     need_rep: bool = False
+    # extension (not a reference field; default keeps the reference's behaviour on the hot path): also materialise
+    # `last_layer_output` [B, N, E] — the reference always computes it (_common.py:212-215), here only the class / EOT row is
+    # projected unless asked ("producible on request")
+    need_last_layer_output: bool = False
 
 
 @dataclass
 class _EncoderOutput:
     last_representation: Optional[torch.Tensor] = None      # [B, E]  class token (image) / EOT token (text)
-    last_layer_output: Optional[torch.Tensor] = None        # [B, N, E]; not materialised on the HIP path (fine_grain only)
+    last_layer_output: Optional[torch.Tensor] = None        # [B, N, E]; only with ControlOutput.need_last_layer_output, or
+                                                            # later from `encoder.last_layer_output()` (detached)
     attention_scores: Optional[List[torch.Tensor]] = field(default_factory=list)
     attention_probs: Optional[List[torch.Tensor]] = field(default_factory=list)
     representations: Optional[List[torch.Tensor]] = field(default_factory=list)

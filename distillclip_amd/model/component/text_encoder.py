@@ -48,11 +48,17 @@ class TextEncoder(nn.Module):
         if co.need_attn_score or co.need_attn_prob or co.need_value_map:
             raise NotImplementedError('teacher attention maps are not exported by the HIP tower (SURVEY.md §2.1)')
         with torch.no_grad():   # hidden states only for `need_layers` (reference _common.py:154-158)
-            hint = self.max_tokens if (self.max_tokens and not co.need_rep and not co.need_emb) else 0
+            want_all = getattr(co, 'need_last_layer_output', False)
+            hint = self.max_tokens if (self.max_tokens and not co.need_rep and not co.need_emb and not want_all) else 0
             out, _, reps, emb = self._tower.forward(text, training=False, need_rep=co.need_rep, need_emb=co.need_emb,
                                                     rep_layers=list(self.need_layers) if self.need_layers is not None else None,
                                                     tokens_eff=min(int(hint), self.context_length))
-        return TextTransformerOutput(last_representation=out, representations=reps, embedding=emb)
+        llo = self._tower.last_layer_output() if want_all else None
+        return TextTransformerOutput(last_representation=out, last_layer_output=llo, representations=reps, embedding=emb)
+
+    def last_layer_output(self):
+        """[B, N, E] = ln_final(x) @ text_projection for every token of the most recent forward (text_encoder.py:69-72)"""
+        return self._tower.last_layer_output()
 
     def forward(self, text, control_output: ControlOutput = None):
         return self.encode_text(text, control_output)

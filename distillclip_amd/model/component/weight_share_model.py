@@ -143,6 +143,10 @@ class _StudentBase(nn.Module):
     def hyper_para(self):
         return self.hyper
 
+    def last_layer_output(self):
+        """[B, N, E] all-token output of norm + head for the most recent forward (weight_share_model.py:363-366, :503-506)"""
+        return self._tower.last_layer_output()
+
     def _check_control(self, co: Optional[ControlOutput]):
         if co is not None and (co.need_attn_score or co.need_attn_prob or co.need_value_map):
             raise NotImplementedError('the HIP towers keep attention scores / probabilities / value maps on chip; the loss terms '
@@ -196,7 +200,8 @@ class RepeatVisionTransformer(_StudentBase):
         co = control_output or ControlOutput()
         rep, hidden, emb = run_tower(self._tower, x, self._anchor_for(x.device), co.need_rep, co.need_emb)
         # like the reference, EVERY block execution contributes a hidden state (weight_share_model.py:211, :356-357)
-        return VisionTransformerOutput(last_representation=rep, representations=hidden, embedding=emb)
+        llo = self._tower.last_layer_output() if getattr(co, 'need_last_layer_output', False) else None
+        return VisionTransformerOutput(last_representation=rep, last_layer_output=llo, representations=hidden, embedding=emb)
 
     def forward(self, x, control_output: ControlOutput = None):
         return self.forward_features(x, control_output)
@@ -257,7 +262,8 @@ class RepeatTextTransformer(_StudentBase):
         self._check_control(control_output)
         co = control_output or ControlOutput()
         rep, hidden, emb = run_tower(self._tower, text, self._anchor_for(text.device), co.need_rep, co.need_emb)
-        return TextTransformerOutput(last_representation=rep, representations=hidden, embedding=emb)
+        llo = self._tower.last_layer_output() if getattr(co, 'need_last_layer_output', False) else None
+        return TextTransformerOutput(last_representation=rep, last_layer_output=llo, representations=hidden, embedding=emb)
 
     def forward(self, x, control_output: ControlOutput = None):
         return self.forward_features(x, control_output)

@@ -68,17 +68,32 @@ class DistillModel(nn.Module):
         self.last_cal_res = cal_res
         return loss
 
+    def towers(self):
+        return [self.student._tower]
+
+    def _ensure_sync(self):
+        """data-parallel plumbing of the student towers (lazy: torch.distributed may be initialised after __init__)"""
+        self._sync = GradSync.current(self._sync).attach(self.towers())
+        return self._sync
+
     def backward_and_sync(self, loss, defer_wait=False):
-        """loss.backward() + the DDP gradient average of the reference's strategy (ddp_find_unused_parameters_false)."""
-        loss.backward()
-        if self._sync is None:
-            self._sync = GradSync()
+        """loss.backward() + the data-parallel gradient exchange (reference strategy ddp_find_unused_parameters_false):
+        bucketed reduce-scatter released from inside the backward + sharded AdamW + parameter all-gather (parallel.py)."""
+        sync = self._ensure_sync()
+        if loss is not None:
+            loss.backward()
+        if not sync.enabled:
+            return
         tw = self.student._tower
-        tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
-        if not defer_wait:       # defer_wait: FusedAdamW.step(overlap=True) waits per tower on `grads_ready` instead
-            self._sync.wait()
+        if tw.dp is not None:
+            tw.grads_ready = sync.finish(tw)
+            tw._grad_clean = True
         else:
-            self._sync.forget()
+            tw.grads_ready = sync.launch(tw.flat_grad, after=tw.bwd_done)
+        if not defer_wait:
+            sync.wait()
+        else:
+            sync.forget()
 
     def _acc(self, log, rows, cols, section, prefix, acc=True, score=False):
         # reference norm_and_logits :224-231 builds stu_logits = stu_encode @ encode.T : rows = this tower, cols = the other
@@ -123,6 +138,7 @@ class DistillModel(nn.Module):
         self.student._tower.materialize(next(self.student.parameters()).device)
         opt = FusedAdamW([self.student._tower], lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
         sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
+        self._ensure_sync()          # data-parallel run: shard plan over the same trainable set the optimizer was built with
         return [opt], [sched]
 
     def on_train_epoch_start(self):

@@ -159,19 +159,31 @@ class DualDistillModel(nn.Module):
         self.last_cal_res = cal_res
         return loss
 
+    def _ensure_sync(self):
+        """data-parallel plumbing of the student towers (lazy: torch.distributed may be initialised after __init__)"""
+        self._sync = GradSync.current(self._sync).attach(self.towers())
+        return self._sync
+
     def backward_and_sync(self, loss, defer_wait=False):
-        """loss.backward() + DDP gradient averaging (reference strategy ddp_find_unused_parameters_false, l_clip.yaml:56).
-        Each tower's flat gradient buffer is exchanged on a side stream right after its backward has been enqueued."""
+        """loss.backward() + the data-parallel gradient exchange (reference strategy ddp_find_unused_parameters_false,
+        l_clip.yaml:56).  Sharded mode: every gradient bucket is reduce-scattered from inside its tower's backward (per-block
+        release, reverse layer order) and FusedAdamW.step() updates the owned shards and all-gathers the parameters; fallback:
+        each tower's flat buffer is all-reduced on a side stream right after its backward has been enqueued."""
+        sync = self._ensure_sync()
         if loss is not None:                                   # None: the caller already ran loss.backward()
             loss.backward()
-        if self._sync is None:
-            self._sync = GradSync()
+        if not sync.enabled:
+            return
         for tw in self.towers():
-            tw.grads_ready = self._sync.launch(tw.flat_grad, after=tw.bwd_done)
-        if not defer_wait:       # defer_wait: FusedAdamW.step(overlap=True) waits per tower on `grads_ready` instead
-            self._sync.wait()
+            if tw.dp is not None:
+                tw.grads_ready = sync.finish(tw)
+                tw._grad_clean = True                          # exchanged buckets were cleared behind their reduce-scatter
+            else:
+                tw.grads_ready = sync.launch(tw.flat_grad, after=tw.bwd_done)
+        if not defer_wait:       # defer_wait: FusedAdamW.step waits per tower on `grads_ready` / runs on the exchange stream
+            sync.wait()
         else:
-            self._sync.forget()
+            sync.forget()
 
     def _acc(self, log, img, txt, section, prefix, acc=True, score=False):
         m = retrieval_metrics(img, txt, self.k_list)
@@ -219,6 +231,7 @@ class DualDistillModel(nn.Module):
             tw.materialize(dev)
         opt = FusedAdamW(self.towers(), lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
         sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
+        self._ensure_sync()          # data-parallel run: shard plan over the same trainable set the optimizer was built with
         return [opt], [sched]
 
     def on_train_epoch_start(self):

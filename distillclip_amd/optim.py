@@ -17,7 +17,13 @@ def cosine_with_warmup(step, warm, total):
 
 
 class FusedAdamW:
-    """One dclip_adamw launch per contiguous trainable range of each tower's flat buffer."""
+    """One dclip_adamw launch per contiguous trainable range of each tower's flat buffer.
+
+    The trainable set is fixed when the optimizer is built, like the reference's AdamW(filter(requires_grad, parameters()))
+    (dual_distill_model.py:195, distil_model.py:161): parameters unfrozen later (unfreeze_embed) do not enter it.
+
+    Data-parallel runs (tower.dp set by parallel.GradSync.plan): each rank updates only its 1/W shard of every gradient bucket
+    from the reduce-scattered average, keeps m / v for that shard only, and the updated parameters are all-gathered."""
 
     def __init__(self, towers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.towers = list(towers)
@@ -25,23 +31,26 @@ class FusedAdamW:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = 0
         self._state = {}
+        self._fixed_ranges = {}
+        for tw in self.towers:
+            if tw.flat is not None:
+                self._fixed_ranges[id(tw)] = [list(r) for r in tw.trainable_ranges()]
         # overlap mode only: also re-cast the bf16 weight cache right after the update.  Off by default: the re-cast of the NEXT
         # forward runs under the teacher towers' forward (4 streams wide), which hides it better than the end of the step does
         self.refresh_cache_in_step = False
 
     def _ranges(self, tw):
-        """contiguous [begin, end) element ranges of trainable parameters inside tw.flat"""
-        live = [p for p in tw._params() if p is not None]
-        out = []
-        for p, off in zip(live, tw._offsets):
-            if not p.requires_grad:
-                continue
-            end = off + (p.numel() + 63) // 64 * 64
-            if out and out[-1][1] == off:
-                out[-1][1] = end
-            else:
-                out.append([off, end])
-        return out
+        """contiguous [begin, end) element ranges of the parameters this optimizer was built over"""
+        r = self._fixed_ranges.get(id(tw))
+        if r is None:                                  # tower materialised after construction: captured at first use
+            r = self._fixed_ranges[id(tw)] = [list(x) for x in tw.trainable_ranges()]
+        return r
+
+    def _adamw(self, p, g, m, v, zero_grad, st):
+        """p, g, m, v: equally long 1-D f32 views.  (tests/test_parallel_cpu.py substitutes a torch version to rehearse the
+        sharded bookkeeping over gloo; the product path is the HIP kernel.)"""
+        lib().dclip_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
 
     def zero_grad(self, set_to_none=False):
         for tw in self.towers:
@@ -53,6 +62,45 @@ class FusedAdamW:
         r = self._ranges(tw)
         return len(r) == 1 and r[0][0] == 0 and r[0][1] >= tw.flat.numel()
 
+    @staticmethod
+    def _sharded(tw):
+        return getattr(tw, 'dp', None) is not None and getattr(tw, 'sync', None) is not None and tw.sync.enabled
+
+    def _moments(self, tw):
+        key = id(tw)
+        n = tw.dp.shard_elems if self._sharded(tw) else tw.flat.numel()
+        if key not in self._state or self._state[key][0].numel() != max(n, 1):
+            self._state[key] = (torch.zeros(max(n, 1), dtype=torch.float32, device=tw.flat.device),
+                                torch.zeros(max(n, 1), dtype=torch.float32, device=tw.flat.device))
+        return self._state[key]
+
+    def _step_sharded(self, tw):
+        """reduce-scattered gradient shards -> AdamW on the owned slices -> all-gather of the updated parameters, all on the
+        exchange stream behind the tower's reduce-scatters (which were released from inside its backward)."""
+        import torch.distributed as dist
+        sync = tw.sync
+        m, v = self._moments(tw)
+        s = sync.stream_for(tw.flat)
+        works = []
+        with sync._On(s):
+            st = s.cuda_stream if s is not None else None
+            for i, b in enumerate(tw.dp.buckets):
+                if b is None:
+                    continue
+                b0, b1, o0, o1, off, own_tr = b
+                for a, e in own_tr:
+                    lo, hi = off + a - o0, off + e - o0
+                    self._adamw(tw.flat[a:e], tw.gshard[lo:hi], m[lo:hi], v[lo:hi], False, st)
+                works.append(dist.all_gather_into_tensor(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True))
+            for w in works:
+                w.wait()
+        tw.wcache_dirty = True
+        tw.grads_ready = None
+        if s is not None:
+            tw.opt_done = torch.cuda.Event()
+            tw.opt_done.record(s)
+        return s
+
     @torch.no_grad()
     def step(self, zero_grad=False, overlap=False, join=True):
         """zero_grad=True: the kernel clears each gradient element once it has consumed it (saves the separate 306 MB fill that
@@ -60,22 +108,24 @@ class FusedAdamW:
         backward, so a fully trainable tower stays clean until its next backward.
 
         overlap=True: each tower is updated on the stream its backward ran on, as soon as that backward (and, under data
-        parallelism, that tower's gradient all-reduce) is done, followed by the re-cast of its bf16 weight cache — the shorter
+        parallelism, that tower's gradient exchange) is done, followed by the re-cast of its bf16 weight cache — the shorter
         tower's update then runs under the longer tower's backward instead of alone at the end of the step.  The current stream
         is ordered after every tower's update before step() returns, unless join=False: then only the tower streams carry the
-        dependency (backward -> all-reduce -> update -> next forward of that tower) and the next step's frozen teacher towers
+        dependency (backward -> exchange -> update -> next forward of that tower) and the next step's frozen teacher towers
         may start while the last gradient exchange and update are still running; join() orders the current stream after them
         (zero_grad() and state_dict() call it)."""
         self.step_count += 1
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
         joined = []
         for tw in self.towers:
             if tw.flat is None:
                 continue
-            key = id(tw)
-            if key not in self._state or self._state[key][0].numel() != tw.flat.numel():
-                self._state[key] = (torch.zeros_like(tw.flat), torch.zeros_like(tw.flat))
-            m, v = self._state[key]
+            if self._sharded(tw):
+                s = self._step_sharded(tw)
+                if s is not None:
+                    joined.append(s)
+                continue
+            m, v = self._moments(tw)
             stream = tw.bwd_stream if (overlap and getattr(tw, 'bwd_stream', None) is not None) else main
             if stream != main:
                 stream.wait_stream(main)                     # whatever the caller enqueued before step() (e.g. zero_grad of others)
@@ -85,9 +135,7 @@ class FusedAdamW:
             with torch.cuda.stream(stream):
                 st = stream.cuda_stream
                 for b, e in self._ranges(tw):
-                    lib().dclip_adamw(tw.flat.data_ptr() + b * 4, tw.flat_grad.data_ptr() + b * 4, m.data_ptr() + b * 4,
-                                      v.data_ptr() + b * 4, e - b, self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
+                    self._adamw(tw.flat[b:e], tw.flat_grad[b:e], m[b:e], v[b:e], zero_grad, st)
                 tw.wcache_dirty = True
                 tw._grad_clean = bool(zero_grad) and self._ranges_cover_everything(tw)
                 if overlap and self.refresh_cache_in_step:
@@ -105,12 +153,21 @@ class FusedAdamW:
 
     def join(self):
         """order the current stream after every tower's pending (un-joined) update"""
+        if not torch.cuda.is_available():
+            return
         cur = torch.cuda.current_stream()
         for tw in self.towers:
             ev = getattr(tw, 'opt_done', None)
             if ev is not None:
                 cur.wait_event(ev)
                 tw.opt_done = None
+
+    def _full_moments(self, tw):
+        """(m, v) in the flat layout of the tower; collective in a sharded data-parallel run (all-gather of the ranks' shards)"""
+        m, v = self._moments(tw)
+        if self._sharded(tw):
+            return tw.sync.gather_full(tw, m), tw.sync.gather_full(tw, v)
+        return m, v
 
     # ---- torch.optim.AdamW-compatible (de)serialisation: what a Lightning checkpoint stores under 'optimizer_states' ----
     def _slots(self, params=None):
@@ -120,16 +177,20 @@ class FusedAdamW:
             if tw.flat is None:
                 continue
             live = [p for p in tw._params() if p is not None]
+            rng = self._ranges(tw)
             for p, off in zip(live, tw._offsets):
-                if p.requires_grad:
+                if any(a <= off < b for a, b in rng):        # the set captured at construction, not the live flags
                     where[p.data_ptr()] = (tw, off, p.numel(), tuple(p.shape))
         if params is None:
             return list(where.values())
         out = []
         for p in params:
-            if not p.requires_grad:
+            if p.data_ptr() not in where and not p.requires_grad:
                 continue
             if p.data_ptr() not in where:
+                if any(p.data_ptr() == q.data_ptr() for tw in self.towers if tw.flat is not None
+                       for q in tw._params() if q is not None):
+                    continue                                  # unfrozen after the optimizer was built: not one of its slots
                 raise ValueError('FusedAdamW.state_dict: a trainable parameter is not a view of a tower buffer')
             out.append(where[p.data_ptr()])
         return out
@@ -140,9 +201,10 @@ class FusedAdamW:
         self.join()
         slots = self._slots(params)
         state = {}
+        full = {id(tw): self._full_moments(tw) for tw in self.towers if id(tw) in self._state}
         for i, (tw, off, n, shape) in enumerate(slots):
-            if id(tw) in self._state:
-                m, v = self._state[id(tw)]
+            if id(tw) in full:
+                m, v = full[id(tw)]
                 state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': m[off:off + n].view(shape).clone(),
                             'exp_avg_sq': v[off:off + n].view(shape).clone()}
         group = {'lr': self.lr, 'initial_lr': self.base_lr, 'betas': tuple(self.betas), 'eps': self.eps,
@@ -164,13 +226,20 @@ class FusedAdamW:
             st = sd['state'].get(i, sd['state'].get(str(i)))
             if st is None:
                 continue
-            if id(tw) not in self._state:
-                self._state[id(tw)] = (torch.zeros_like(tw.flat), torch.zeros_like(tw.flat))
-            m, v = self._state[id(tw)]
             if tuple(st['exp_avg'].shape) != shape:
                 raise ValueError(f"FusedAdamW.load_state_dict: parameter {i} has shape {shape}, saved {tuple(st['exp_avg'].shape)}")
-            m[off:off + n].copy_(st['exp_avg'].reshape(-1))
-            v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            m, v = self._moments(tw)
+            if self._sharded(tw):
+                # keep the slices of this parameter that fall into the shards this rank owns
+                for b in tw.dp.live():
+                    b0, b1, o0, o1, soff, _ = b
+                    lo, hi = max(off, o0), min(off + n, o1)
+                    if lo < hi:
+                        m[soff + lo - o0:soff + hi - o0].copy_(st['exp_avg'].reshape(-1)[lo - off:hi - off])
+                        v[soff + lo - o0:soff + hi - o0].copy_(st['exp_avg_sq'].reshape(-1)[lo - off:hi - off])
+            else:
+                m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
             steps.add(int(float(st['step'])))
         if len(steps) > 1:
             raise ValueError('FusedAdamW.load_state_dict: parameters with different step counts (one fused step counter here)')
@@ -192,8 +261,15 @@ class EpochCosineSchedule:
         return [self.opt.lr]
 
     def state_dict(self):
-        return {'last_epoch': self.epoch, 'warm_steps': self.warm, 'total_steps': self.total, '_last_lr': [self.opt.lr]}
+        """LambdaLR-shaped (what the reference's scheduler — transformers.get_cosine_schedule_with_warmup, a LambdaLR — saves
+        and what its load_state_dict updates from: base_lrs, last_epoch, _step_count, _last_lr, lr_lambdas=[None] for a
+        plain function), plus the two schedule constants under their own keys"""
+        return {'base_lrs': [self.opt.base_lr], 'last_epoch': self.epoch, 'verbose': False, '_step_count': self.epoch + 1,
+                '_get_lr_called_within_step': False, '_last_lr': [self.opt.lr], 'lr_lambdas': [None],
+                'warm_steps': self.warm, 'total_steps': self.total}
 
     def load_state_dict(self, sd):
         self.epoch = sd['last_epoch']
+        if sd.get('base_lrs'):
+            self.opt.base_lr = sd['base_lrs'][0]
         self.opt.lr = self.opt.base_lr * cosine_with_warmup(self.epoch, self.warm, self.total)

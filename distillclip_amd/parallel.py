@@ -1,41 +1,187 @@
-"""Data-parallel gradient exchange over RCCL (torch.distributed backend "nccl" on ROCm), one process per GPU.
+"""Data-parallel exchange over RCCL (torch.distributed backend "nccl" on ROCm), one process per GPU.
 
-Reference behaviour: Lightning DDP all-reduces the student's f32 gradients.  Here every tower
-already keeps its gradients in ONE flat f32 buffer, so the exchange is a handful of large collectives issued on a
-side HIP stream; the image tower's exchange overlaps the text tower's backward (and vice versa) by construction of
-`GradSync.launch(tower)` being called as soon as a tower's backward call has been enqueued.
+Reference behaviour (SURVEY.md §2.2 C1, §8e Collective 1): Lightning DDP (`ddp_find_unused_parameters_false`,
+config/final_config/l_clip.yaml:56) all-reduces the student's f32 gradients in buckets released by autograd hooks and every
+rank runs the same AdamW (dual_distill_model.py:194-196).  Here every tower keeps its gradients in ONE flat f32 buffer whose
+layout follows the backward's completion order, so the exchange is
+
+    per gradient bucket (final norm + head, blocks L-1 .. 0, embedding), as soon as the backward has enqueued its last writer:
+        reduce-scatter (AVG) of the bucket  ->  this rank's 1/W shard                          [side stream, under the backward]
+    optimizer step:
+        fused AdamW on the owned shard of every bucket (m / v exist only for the shard)  ->  all-gather of the parameters
+
+i.e. reduce-scatter -> sharded AdamW -> all-gather instead of all-reduce + W identical full-size updates: the same bytes on
+the xGMI links, 1/W of the optimizer's HBM traffic and state.  `GradSync.launch` (flat all-reduce) remains as the fallback for
+world sizes that do not divide the 64-element parameter alignment.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+class _Shards:
+    """Per-tower plan: which flat ranges travel together and which slice of each this rank owns."""
+
+    def __init__(self, buckets, trainable, rank, world):
+        # buckets: [(begin, end)] flat element ranges in backward-completion order; trainable: [[begin, end)] ranges
+        self.rank, self.world = rank, world
+        self.buckets = []                       # (begin, end, own_begin, own_end, shard_offset, [trainable ranges inside own])
+        off = 0
+        for (b0, b1) in buckets:
+            tr = [(max(a, b0), min(b, b1)) for a, b in trainable if max(a, b0) < min(b, b1)]
+            if b1 <= b0 or not tr:
+                self.buckets.append(None)       # empty or frozen: never written by the backward, nothing to exchange
+                continue
+            n = b1 - b0
+            if n % world:
+                raise ValueError(f'bucket of {n} elements is not divisible by the world size {world}')
+            per = n // world
+            o0, o1 = b0 + rank * per, b0 + (rank + 1) * per
+            own_tr = [(max(a, o0), min(b, o1)) for a, b in tr if max(a, o0) < min(b, o1)]
+            self.buckets.append((b0, b1, o0, o1, off, own_tr))
+            off += per
+        self.shard_elems = off
+
+    def live(self):
+        return [b for b in self.buckets if b is not None]
+
+
 class GradSync:
-    def __init__(self, bucket_elems=32 * 1024 * 1024):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = dist.get_world_size() if self.enabled else 1
+    """Gradient exchange of the student towers.  `sharded` (default, DCLIP_DP_MODE != 'allreduce'): bucketed reduce-scatter
+    released from inside the backward + sharded optimizer + parameter all-gather; otherwise the flat all-reduce of round 1."""
+
+    def __init__(self, bucket_elems=32 * 1024 * 1024, sharded=None):
+        self.enabled = _dist_on() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if _dist_on() else 1
+        self.rank = dist.get_rank() if _dist_on() else 0
         self.bucket = bucket_elems
+        if sharded is None:
+            sharded = os.environ.get('DCLIP_DP_MODE', 'reduce_scatter') != 'allreduce'
+        self.sharded = bool(sharded) and 64 % max(self.world, 1) == 0      # parameter segments are 64-element aligned
         self._stream = None
         self._pending = []
 
+    @staticmethod
+    def current(existing=None):
+        """the GradSync a model should use now: torch.distributed may have been initialised after the last call"""
+        if existing is None or (not existing.enabled and _dist_on() and dist.get_world_size() > 1):
+            return GradSync()
+        return existing
+
+    def attach(self, towers):
+        """bind the student towers: in sharded mode, plan the buckets / shards of every materialised tower once"""
+        for tw in towers:
+            tw.sync = self
+            if self.enabled and self.sharded and tw.dp is None and tw.flat is not None:
+                self.plan(tw, tw.trainable_ranges())
+        return self
+
+    # ---- stream plumbing (no-ops for the gloo / CPU rehearsal of the same call pattern) ---------------------------
+    def stream_for(self, t):
+        if not t.is_cuda:
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=t.device)
+        return self._stream
+
+    class _On:
+        def __init__(self, stream):
+            self.ctx = torch.cuda.stream(stream) if stream is not None else None
+
+        def __enter__(self):
+            if self.ctx is not None:
+                self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+
+    # ---- sharded mode ------------------------------------------------------------------------------------------------
+    def plan(self, tw, trainable):
+        """attach the shard plan of tower `tw` (HipTower or any object with .flat / .flat_grad / .grad_buckets())."""
+        sh = _Shards(tw.grad_buckets(), trainable, self.rank, self.world)
+        tw.dp = sh
+        tw.gshard = torch.zeros(max(sh.shard_elems, 1), dtype=torch.float32, device=tw.flat.device)
+        tw.dp_released = 0
+        return sh
+
+    def bucket_ready(self, tw, i, after=None):
+        """Called (on the thread that issues the backward, current stream = the backward's stream) as soon as every launch that
+        writes bucket i of `tw.flat_grad` has been enqueued: average it across ranks into this rank's shard.  `after`: event that
+        marks the bucket complete (default: everything enqueued on the current stream so far)."""
+        sh = tw.dp
+        b = sh.buckets[i]
+        tw.dp_released = max(tw.dp_released, i + 1)
+        if b is None:
+            return
+        b0, b1, o0, o1, off, _ = b
+        g = tw.flat_grad
+        s = self.stream_for(g)
+        if s is not None:
+            if after is None:
+                after = torch.cuda.Event()
+                after.record(torch.cuda.current_stream())
+            s.wait_event(after)
+        with GradSync._On(s):
+            out = tw.gshard[off:off + (o1 - o0)]
+            if g.is_cuda:
+                dist.reduce_scatter_tensor(out, g[b0:b1], op=dist.ReduceOp.AVG)
+            else:                                       # gloo has no AVG
+                dist.reduce_scatter_tensor(out, g[b0:b1], op=dist.ReduceOp.SUM)
+                out.mul_(1.0 / self.world)
+            g[b0:b1].zero_()                            # the backward accumulates (+=): leave the bucket clean for the next step
+
+    def finish(self, tw):
+        """after the backward call: release whatever the callbacks did not (a backward without per-bucket callbacks)"""
+        for i in range(tw.dp_released, len(tw.dp.buckets)):
+            self.bucket_ready(tw, i, after=getattr(tw, 'bwd_done', None))
+        tw.dp_released = 0
+        if tw.flat_grad.is_cuda and self._stream is not None:
+            done = torch.cuda.Event()
+            done.record(self._stream)
+            return done
+        return None
+
+    def gather_params(self, tw, i):
+        """all-gather bucket i of the parameters from the ranks' updated shards (call on the exchange stream)"""
+        b = tw.dp.buckets[i]
+        if b is None:
+            return
+        b0, b1, o0, o1, _, _ = b
+        dist.all_gather_into_tensor(tw.flat[b0:b1], tw.flat[o0:o1])
+
+    def gather_full(self, tw, shard):
+        """[shard_elems] per-rank optimizer state -> full flat-layout tensor (checkpointing; collective)"""
+        full = torch.zeros_like(tw.flat)
+        for b in tw.dp.live():
+            b0, b1, o0, o1, off, _ = b
+            dist.all_gather_into_tensor(full[b0:b1], shard[off:off + (o1 - o0)].contiguous())
+        return full
+
+    # ---- flat all-reduce (fallback; the reference's DDP semantics literally) -----------------------------------------------
     def launch(self, flat_grad, after=None):
         """average `flat_grad` across ranks, asynchronously with respect to the compute stream.  `after`: CUDA event that
         marks the buffer complete (a tower's end-of-backward event); default = everything enqueued on the current stream."""
         if not self.enabled or flat_grad is None:
             return None
         if flat_grad.is_cuda:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream()
+            s = self.stream_for(flat_grad)
             if after is not None:
-                self._stream.wait_event(after)
+                s.wait_event(after)
             else:
-                self._stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._stream):
+                s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
                 for b in range(0, flat_grad.numel(), self.bucket):
                     chunk = flat_grad[b:b + self.bucket]
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG)      # RCCL averages in the collective itself
             self._pending.append(flat_grad)
             done = torch.cuda.Event()
-            done.record(self._stream)              # this buffer's average is complete: a per-tower optimizer step may wait on it
+            done.record(s)              # this buffer's average is complete: a per-tower optimizer step may wait on it
             return done
         else:   # gloo / CPU rehearsal of the same call pattern
             for b in range(0, flat_grad.numel(), self.bucket):
@@ -44,13 +190,29 @@ class GradSync:
                 chunk.mul_(1.0 / self.world)
 
     def wait(self):
-        if self._stream is not None and self._pending:
+        if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         self._pending = []
 
     def forget(self):
-        """the caller carries the dependency itself (per-buffer events returned by launch)"""
+        """the caller carries the dependency itself (per-buffer events returned by launch / finish)"""
         self._pending = []
+
+
+def world_size():
+    return dist.get_world_size() if _dist_on() else 1
+
+
+def check_equal_batch(B, device):
+    """Global-negative mode addresses gathered rows as rank * B: every rank must hold the same B (a loader without drop_last
+    would desynchronise the collectives).  One tiny all-reduce of (B, -B); raises the same error on every rank."""
+    if not _dist_on() or dist.get_world_size() == 1:
+        return
+    t = torch.tensor([float(B), -float(B)], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    bmax, bmin = int(t[0].item()), int(-t[1].item())
+    if bmax != bmin:
+        raise ValueError(f'global negatives need the same per-rank batch on every rank (got {bmin}..{bmax}): use drop_last=True')
 
 
 def gather_embeddings(tensors):
@@ -60,7 +222,7 @@ def gather_embeddings(tensors):
     gathered batch and keeps the gradient rows of its own shard, so no reduce-scatter of embedding gradients is needed; the
     gradient is scaled by `world` so that the DDP *average* of parameter gradients equals the single-process gradient of the
     loss on the concatenated batch."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _dist_on():
         return list(tensors), 0, 1
     world, rank = dist.get_world_size(), dist.get_rank()
     packed = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()          # [B, k*E]: one fused gather

@@ -5,7 +5,9 @@
  * The boundary this library replaces is therefore the implicit ATen kernel sequence behind the reference's
  * nn.Module calls.  Each entry point cites the reference call site (file:line under the reference root) whose
  * arithmetic it implements.  All pointers are raw device pointers; `stream` is a hipStream_t passed as void*.
- * No allocation, no synchronisation and no global mutable state inside any entry point; every function returns
+ * No allocation and no synchronisation inside any entry point, and no global mutable state on the compute path: the only
+ * process-global state is the opt-in launch trace (dclip_trace_*, mutex-guarded, profiling only) and the tuning knobs read
+ * from DCLIP_* environment variables, which are latched once on first use.  Every function returns
  * 0 on success, DCLIP_EINVAL (-1) for a bad argument, DCLIP_ELAUNCH (-2) for a HIP launch failure, and
  * dclip_last_error_string() (thread-local) explains the last failure.
  *
@@ -305,9 +307,26 @@ int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, v
 int dclip_encoder_forward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                           const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
                           float* const* rep_out, float* emb_out, int64_t tokens_eff, void* stream);
+/* last_layer_output (reference output.py:16-35; _common.py:210-215, text_encoder.py:69-72, weight_share_model.py:363-366,
+ * :503-506): final norm + projection of EVERY token, f32 [B*N, E], computed on request from the residual stream the most
+ * recent dclip_encoder_forward(enc, ..., B, training) left in `workspace` (tokens_eff must have been 0).  scratch: bf16
+ * [B*N, D] caller-owned.  last_representation is the class-token / EOT row of this tensor. */
+int dclip_encoder_last_layer_output(const dclip_encoder* enc, int64_t B, const void* const* params, const void* wcache,
+                                    void* workspace, size_t ws_bytes, int training, void* scratch, float* out, void* stream);
+/* on_bucket (nullable): host callback, invoked on the calling thread as soon as every launch that writes gradient bucket
+ * `bucket` has been enqueued on `stream` (an event recorded on `stream` inside the callback marks the bucket complete): the
+ * data-parallel exchange of that bucket may start while the rest of the backward runs (reference: Lightning DDP's bucketed
+ * all-reduce from autograd hooks, config/final_config/l_clip.yaml:56 strategy ddp_find_unused_parameters_false).
+ * Buckets complete in index order; see dclip_encoder_grad_bucket. */
+typedef void (*dclip_bucket_cb)(void* user, int32_t bucket);
 int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
-                           const float* d_last_representation, const float* const* d_rep, const float* d_emb, void* stream);
+                           const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                           dclip_bucket_cb on_bucket, void* cb_user, void* stream);
+/* gradient buckets in completion order: 0 = final norm + head, 1..L = blocks L-1..0, L+1 = embedding parameters; each is the
+ * range [first_param, end_param) of the canonical parameter order above. */
+int32_t dclip_encoder_num_grad_buckets(const dclip_encoder* enc);
+int dclip_encoder_grad_bucket(const dclip_encoder* enc, int32_t bucket, int32_t* first_param, int32_t* end_param);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Launch trace (profiling only; process-global): between begin and end every GEMM / LayerNorm-forward / loss call is

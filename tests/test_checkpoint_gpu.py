@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from distillclip_amd import synth
+from distillclip_amd import synth, checkpoint
 
 pytestmark = pytest.mark.gpu
 
@@ -257,3 +257,94 @@ def test_unjoined_overlapped_step_with_deferred_sync_matches_plain():
     for k, v in a.items():
         w = ck['state_dict']['student.' + k]
         assert (v.cpu() - w).norm().item() <= 5e-4 * (w.norm().item() + 1e-12), k
+
+
+def test_optimizer_keeps_the_trainable_set_it_was_built_with():
+    """reference dual_distill_model.py:195 / distil_model.py:161: AdamW(filter(requires_grad, parameters())) is built once;
+    parameters unfrozen later (unfreeze_embed) never enter it.  Here: frozen embeddings stay put after unfreeze_embed() and the
+    optimizer's state_dict keeps its slot count (checkpoints stay loadable)."""
+    from distillclip_amd.model import DistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer
+    cfg = dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4, mlp_ratio=4.0,
+               qkv_bias=True, repeated_times=2, use_transform=True)
+    seed = 5
+    s = RepeatVisionTransformer(**cfg)
+    s.load_state_dict(T(synth.student_image_state(seed, **cfg)))
+    tsd = T(synth.teacher_image_state(seed, 128, 2, 8, 32, 64))
+    tsd.update(T(synth.teacher_text_state(seed, 128, 2, 13, 97, 64)))
+    m = DistillModel(s, dict(loss_name=['out_l1', 'out_cos']), '.', freeze_embed=True, model_type='image', lr=1e-2,
+                     warm_steps=0, teacher_state_dict=tsd).cuda()
+    (opt,), _ = m.configure_optimizers()
+    n_slots = len(opt.state_dict(checkpoint.trainable_parameters(m))['param_groups'][0]['params'])
+    image = torch.from_numpy(synth.images(seed, 4, 32)).cuda()
+    m.unfreeze_embed()                                   # after the optimizer exists
+    cls0 = dict(m.student.named_parameters())['cls_token'].detach().clone()
+    head0 = dict(m.student.named_parameters())['head.weight'].detach().clone()
+    for _ in range(2):
+        loss = m.training_step(image)
+        opt.zero_grad()
+        m.backward_and_sync(loss)
+        opt.step()
+    torch.cuda.synchronize()
+    named = dict(m.student.named_parameters())
+    assert named['cls_token'].requires_grad and named['cls_token'].grad is not None     # autograd sees it ...
+    assert torch.equal(named['cls_token'].detach(), cls0)                                # ... the optimizer does not
+    assert not torch.equal(named['head.weight'].detach(), head0)
+    sd = opt.state_dict(checkpoint.trainable_parameters(m))
+    assert len(sd['param_groups'][0]['params']) == n_slots == len(sd['state'])
+
+
+def test_reduce_scatter_sharded_path_over_rccl_world1_equals_plain_path():
+    """The data-parallel step (bucket callbacks from inside the backward -> reduce-scatter -> sharded AdamW -> all-gather) on a
+    1-rank RCCL group takes the same optimizer step as the single-process path: same code the N-GPU bench runs, one rank."""
+    import torch.distributed as dist
+    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    from distillclip_amd.parallel import GradSync
+    s_img_cfg = dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4, mlp_ratio=4.0,
+                     qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4.0,
+                     qkv_bias=False, repeated_times=2, use_transform=True)
+    seed, B = 9, 6
+    image = torch.from_numpy(synth.images(seed, B, 32)).cuda()
+    text = torch.from_numpy(synth.captions(seed, B, 13, 97, 3, 9)).cuda()
+
+    def build():
+        si, st = RepeatVisionTransformer(**s_img_cfg), RepeatTextTransformer(**s_txt_cfg)
+        si.load_state_dict(T(synth.student_image_state(seed, **s_img_cfg)))
+        st.load_state_dict(T(synth.student_text_state(seed, **s_txt_cfg)))
+        tsd = T(synth.teacher_image_state(seed, 128, 2, 8, 32, 64))
+        tsd.update(T(synth.teacher_text_state(seed, 128, 2, 13, 97, 64)))
+        return DualDistillModel(si, st, dict(loss_name=['out_cos', 'out_kl'], temperature=2.0), 0, 10, 1e-2, 1e-3, '.',
+                                freeze_prefix=['image_encoder.pos_embed'], teacher_state_dict=tsd).cuda()
+
+    def train(model, steps=3):
+        (opt,), _ = model.configure_optimizers()
+        for _ in range(steps):
+            loss = model.training_step([image, text])
+            opt.zero_grad()
+            model.backward_and_sync(loss, defer_wait=True)
+            opt.step(zero_grad=True, overlap=True, join=False)
+        opt.join()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.student.named_parameters()}, opt
+
+    plain, _ = train(build())
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        model = build()
+        model._sync = GradSync()
+        model._sync.enabled = True                      # world 1: the collectives still run (RCCL), the shard is the whole bucket
+        sharded, opt = train(model)
+        tw = model.towers()[0]
+        assert tw.dp is not None and len(tw.dp.buckets) == tw.cfg.layers + 2 and tw.gshard.numel() >= 1
+        assert float(tw.flat_grad.abs().max()) == 0.0   # exchanged buckets are left clean
+        sd = opt.state_dict(checkpoint.trainable_parameters(model))      # gathers the (1-rank) shards
+        assert len(sd['state']) == len(sd['param_groups'][0]['params'])
+    finally:
+        dist.destroy_process_group()
+    for k in plain:
+        # wgrad atomics are not bit-reproducible between runs: same tolerance as the resume test
+        assert torch.allclose(plain[k], sharded[k], rtol=2e-3, atol=2e-5), (k, (plain[k] - sharded[k]).abs().max())

@@ -114,10 +114,20 @@ def test_l_clip_336px_dual():
     text = torch.from_numpy(synth.captions(seed, B))
     loss = m.training_step([image.cuda(), text.cuda()])
     m.backward_and_sync(loss)
+    for v in list(sdi.values()) + list(sdt.values()):
+        v.requires_grad_(True)
+    oi, ot = oracle.student_image_forward(sdi, image, 24), oracle.student_text_forward(sdt, text, 12)
     with torch.no_grad():
-        oi, ot = oracle.student_image_forward(sdi, image, 24), oracle.student_text_forward(sdt, text, 12)
         ti = oracle.teacher_image_forward({k: v for k, v in tsd.items() if k.startswith('visual.')}, image)
         tt = oracle.teacher_text_forward({k: v for k, v in tsd.items() if not k.startswith('visual.')}, text)
-        ol, _ = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})(oracle.clip_forward(oi, ot), oracle.clip_forward(ti, tt), 'all')
+    ol, _ = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})(oracle.clip_forward(oi, ot), oracle.clip_forward(ti, tt), 'all')
+    ol.backward()
     assert abs(loss.item() - ol.item()) <= 2e-2 * abs(ol.item()), (loss.item(), ol.item())
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.student.parameters())
+    # gradients of the 101-token image student (and the text student next to it) against the oracle's
+    named_i, named_t = dict(si.named_parameters()), dict(st.named_parameters())
+    for n in ('head.weight', 'pos_embed', 'patch_embed.proj.weight', 'blocks.2.block.mlp.fc1.weight', 'blocks.0.block.attn.qkv.weight',
+              'blocks.1.block.attn.proj.weight'):
+        assert rel(named_i[n].grad, sdi[n].grad) < 1.5e-1, ('image', n, rel(named_i[n].grad, sdi[n].grad))
+    for n in ('head.weight', 'blocks.0.block.mlp.fc2.weight', 'blocks.1.block.attn.qkv.weight'):
+        assert rel(named_t[n].grad, sdt[n].grad) < 1.5e-1, ('text', n, rel(named_t[n].grad, sdt[n].grad))

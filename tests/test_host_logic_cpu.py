@@ -106,3 +106,33 @@ def test_teacher_load_without_network(monkeypatch, tmp_path):
     torch.save(_tiny_teacher_sd(), tmp_path / 'ViT-B-32.pt')
     t = utils.teacher_load('ViT-B/32', str(tmp_path), 'all')
     assert t.image_encoder.vit_paras['width'] == 128 and t.text_encoder.layers == 2
+
+
+def test_scheduler_state_loads_into_a_lambda_lr_and_back():
+    """checkpoint 'lr_schedulers' entry: the keys torch's LambdaLR.load_state_dict consumes (the reference's scheduler is
+    transformers.get_cosine_schedule_with_warmup, a LambdaLR stepped per epoch: distil_model.py:164-169)"""
+    import torch
+    from distillclip_amd.optim import EpochCosineSchedule, cosine_with_warmup
+
+    class _Opt:
+        base_lr = lr = 5e-3
+    o = _Opt()
+    s = EpochCosineSchedule(o, 10, 200)
+    for _ in range(7):
+        s.step()
+    sd = s.state_dict()
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.AdamW([p], lr=5e-3)
+    lam = torch.optim.lr_scheduler.LambdaLR(topt, lambda e: cosine_with_warmup(e, 10, 200))
+    lam.load_state_dict(sd)                                    # must not raise; LambdaLR keeps its own lambda for lr_lambdas=[None]
+    assert lam.last_epoch == 7 and abs(lam.get_last_lr()[0] - o.lr) < 1e-12
+    o2 = _Opt()
+    s2 = EpochCosineSchedule(o2, 10, 200)
+    s2.load_state_dict(lam.state_dict())                       # and the reference-side state loads here
+    assert s2.epoch == 7 and abs(o2.lr - o.lr) < 1e-12
+
+
+def test_checkpoint_version_is_parseable():
+    from packaging.version import Version
+    from distillclip_amd import checkpoint
+    assert Version(checkpoint.LIGHTNING_VERSION) < Version('2.0')

@@ -215,3 +215,76 @@ def test_metrics_known_answers():
     for k in (1, 3, 5):
         assert abs(m2[f'acc_top{k}'].item() - (want < k).double().mean().item()) < 1e-12
     assert m2['acc_top1'].item() < m2['acc_top3'].item() <= m2['acc_top5'].item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# B = 4 plumbing run as a loss TRAJECTORY of the reference (tools/golden/gen_golden.py:trajectory):
+# forward + backward + AdamW + per-epoch cosine/warm-up schedule, 16 steps (tiny) / 4 steps (real shapes)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def traj(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, 'trajectory.npz')))
+
+
+def _oracle_train(sd_i, sd_t, t_i, t_t, heads_i, heads_t, batches, lr, wd, warm, total, steps_per_epoch):
+    from distillclip_amd.optim import cosine_with_warmup
+    params = list(sd_i.values()) + list(sd_t.values())
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    lc = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})
+    losses, epoch = [], 0
+    for i, (image, text) in enumerate(batches):
+        for g in opt.param_groups:
+            g['lr'] = lr * cosine_with_warmup(epoch, warm, total)
+        so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, heads_i), oracle.student_text_forward(sd_t, text, heads_t))
+        with torch.no_grad():
+            to = oracle.clip_forward(oracle.teacher_image_forward(t_i, image), oracle.teacher_text_forward(t_t, text))
+        loss, _ = lc(so, to, 'all')
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if (i + 1) % steps_per_epoch == 0:
+            epoch += 1
+    return losses
+
+
+def test_tiny_16_step_trajectory_matches_reference(traj):
+    c = TINY
+    seed, B, n = int(traj['tiny.seed']), int(traj['tiny.B']), 64
+    images = torch.from_numpy(synth.images(seed, n, c['res']))
+    texts = torch.from_numpy(synth.captions(seed, n, c['ctx'], c['vocab'], 3, 9))
+    sd_i = T(synth.student_image_state(seed, **c['s_img']), grad=True)
+    sd_t = T(synth.student_text_state(seed, **c['s_txt']), grad=True)
+    t_i = T(synth.teacher_image_state(seed, 128, 2, c['patch'], c['res'], c['out_dim']))
+    t_t = T(synth.teacher_text_state(seed, 128, 2, c['ctx'], c['vocab'], c['out_dim']))
+    batches = [(images[i:i + B], texts[i:i + B]) for i in range(0, n, B)]
+    losses = _oracle_train(sd_i, sd_t, t_i, t_t, 4, 2, batches, float(traj['tiny.base_lr']), float(traj['tiny.wd']),
+                           int(traj['tiny.warm']), int(traj['tiny.total']), int(traj['tiny.steps_per_epoch']))
+    assert len(losses) == 16
+    np.testing.assert_allclose(losses, traj['tiny.loss'], rtol=2e-4)
+    # epoch 0 of a warm-up schedule runs at lr 0 (HF multiplier 0 / warm): the first 4 batches see the initial weights
+    assert traj['tiny.lr'][0] == 0.0 and traj['tiny.lr'][4] > 0
+    # final weights after 12 effective AdamW steps.  Per-tensor relative L2: the k-part of attn.qkv.bias has an exactly-zero
+    # true gradient (softmax is shift-invariant), so Adam normalises pure rounding noise there and its elements move by
+    # +-lr per step in a run-dependent direction; measured over whole tensors that is < 1e-2 of the bias norm.
+    worst = {}
+    for tag, sd in (('s_img', sd_i), ('s_txt', sd_t)):
+        for name, p in sd.items():
+            ref = traj[f'tiny.{tag}.final.{name}']
+            worst[f'{tag}.{name}'] = float(np.linalg.norm(p.detach().numpy() - ref) / (np.linalg.norm(ref) + 1e-12))
+    bad = {k: v for k, v in worst.items() if v > (2e-2 if 'qkv.bias' in k else 1e-3)}
+    assert not bad, bad
+
+
+def test_real_shapes_4_step_trajectory_matches_reference(traj):
+    seed, B, n = int(traj['real.seed']), int(traj['real.B']), 16
+    cfg_i = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24, mlp_ratio=4.0,
+                 qkv_bias=True, repeated_times=2, use_transform=True)
+    cfg_t = dict(depth=4, repeated_times=2, use_transform=True)
+    images = torch.from_numpy(synth.images(seed, n, 224))
+    texts = torch.from_numpy(synth.captions(seed, n))
+    sd_i, sd_t = T(synth.student_image_state(seed, **cfg_i), grad=True), T(synth.student_text_state(seed, **cfg_t), grad=True)
+    t_i, t_t = T(synth.teacher_image_state(seed)), T(synth.teacher_text_state(seed))
+    batches = [(images[i:i + B], texts[i:i + B]) for i in range(0, n, B)]
+    losses = _oracle_train(sd_i, sd_t, t_i, t_t, 24, 12, batches, float(traj['real.base_lr']), float(traj['real.wd']), 0, 300, 10 ** 9)
+    np.testing.assert_allclose(losses, traj['real.loss'], rtol=5e-4)

@@ -158,3 +158,183 @@ def test_gather_rows_is_identity_without_process_group():
     from distillclip_amd.metrics import gather_rows
     x = torch.randn(4, 8)
     assert gather_rows(x) is x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reduce-scatter -> sharded AdamW -> all-gather (SURVEY.md §8e Collective 1), rehearsed over gloo with the same call pattern
+# the RCCL path uses: GradSync.plan / bucket_ready (what the backward's bucket callback calls) / finish, FusedAdamW.step
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeTower:
+    """flat buffers + bucket layout of a tower, without the HIP runtime (the bookkeeping under test is host logic)"""
+
+    def __init__(self, total, buckets, trainable, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.flat = torch.randn(total, generator=g)
+        self.flat_grad = torch.zeros(total)
+        self._buckets, self._trainable = buckets, trainable
+        self.sync = self.dp = self.gshard = None
+        self.dp_released = 0
+        self.wcache_dirty = False
+        self.grads_ready = self.opt_done = self.bwd_stream = None
+        self._grad_clean = False
+
+        edges = sorted({0, total} | {e for r in trainable for e in r})
+        self._offsets = edges[:-1]
+        self._plist = [self.flat[a:b] for a, b in zip(edges[:-1], edges[1:])]      # one "parameter" per segment
+
+    def _params(self):
+        return self._plist
+
+    def grad_buckets(self):
+        return list(self._buckets)
+
+    def trainable_ranges(self):
+        return [list(r) for r in self._trainable]
+
+
+def _torch_adamw(self, p, g, m, v, zero_grad, st):
+    """torch restatement of dclip_adamw (torch.optim.AdamW semantics) for the CPU rehearsal"""
+    b1, b2 = self.betas
+    p.mul_(1.0 - self.lr * self.weight_decay)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+    p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(self.eps), value=-self.lr / bc1)
+    if zero_grad:
+        g.zero_()
+
+
+# completion order: head bucket at the END of the flat layout, two blocks, a frozen-only bucket, embedding at the start
+_TOTAL = 64 * 40
+_BUCKETS = [(64 * 34, 64 * 40), (64 * 20, 64 * 34), (64 * 12, 64 * 20), (64 * 8, 64 * 12), (0, 64 * 8)]
+_TRAINABLE = [[64 * 2, 64 * 8], [64 * 12, 64 * 25], [64 * 26, 64 * 40]]      # frozen: part of the embedding, bucket 3, one segment
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from distillclip_amd.parallel import GradSync
+    from distillclip_amd.optim import FusedAdamW
+    FusedAdamW._adamw = _torch_adamw
+    tw = _FakeTower(_TOTAL, _BUCKETS, _TRAINABLE, seed=3)              # same parameters on every rank
+    sync = GradSync()
+    assert sync.enabled and sync.sharded
+    sync.attach([tw])
+    opt = FusedAdamW([tw], lr=1e-2, weight_decay=1e-2)
+    mask = torch.zeros(_TOTAL, dtype=torch.bool)
+    for a, b in _TRAINABLE:
+        mask[a:b] = True
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)          # every rank its own gradient; frozen entries stay 0
+        tw.flat_grad.add_(torch.randn(_TOTAL, generator=g) * mask)
+        for i in range(len(_BUCKETS)):                                 # what the backward's bucket callback does, in order
+            sync.bucket_ready(tw, i)
+        sync.finish(tw)
+        assert float(tw.flat_grad.abs().max()) == 0.0                  # exchanged buckets are left clean for the next backward
+        opt.step()
+    sd = opt.state_dict()                                              # collective: gathers the ranks' m / v shards
+    assert tw.dp.shard_elems * world == sum(b1 - b0 for (b0, b1), b in zip(_BUCKETS, tw.dp.buckets) if b is not None)
+    q.put((rank, tw.flat.clone(), {k: {n: t.clone() for n, t in v.items()} for k, v in sd['state'].items()},
+           opt._state[id(tw)][0].numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    ps = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=90) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected: torch.optim.AdamW on the AVERAGED gradients, trainable entries only (what DDP + the reference's optimizer do)
+    ref = _FakeTower(_TOTAL, _BUCKETS, _TRAINABLE, seed=3)
+    mask = torch.zeros(_TOTAL, dtype=torch.bool)
+    for a, b in _TRAINABLE:
+        mask[a:b] = True
+    chunks = [torch.nn.Parameter(ref.flat[a:b].clone()) for a, b in _TRAINABLE]
+    topt = torch.optim.AdamW(chunks, lr=1e-2, weight_decay=1e-2)
+    for step in range(3):
+        avg = sum(torch.randn(_TOTAL, generator=torch.Generator().manual_seed(100 * step + r)) * mask for r in range(world)) / world
+        for c, (a, b) in zip(chunks, _TRAINABLE):
+            c.grad = avg[a:b].clone()
+        topt.step()
+    want = ref.flat.clone()
+    for c, (a, b) in zip(chunks, _TRAINABLE):
+        want[a:b] = c.detach()
+    for rank, flat, state, nshard in res:
+        assert torch.allclose(flat, want, rtol=1e-5, atol=1e-6), (rank, (flat - want).abs().max())
+        assert torch.equal(flat[~mask], ref.flat[~mask])               # frozen parameters untouched
+        assert nshard * world < _TOTAL                                 # m / v exist for the owned shards only
+    # the gathered optimizer state equals torch's (first trainable range = the first slots)
+    (_, _, st0, _), (_, _, st1, _) = sorted(res, key=lambda r: r[0])
+    assert st0.keys() == st1.keys() and len(st0) == len(_TRAINABLE)
+    tstate = topt.state_dict()['state']
+    for i in range(len(_TRAINABLE)):
+        for st in (st0, st1):                                          # every rank sees the full (gathered) moments
+            assert torch.allclose(st[i]['exp_avg'], tstate[i]['exp_avg'], rtol=1e-5, atol=1e-7)
+            assert torch.allclose(st[i]['exp_avg_sq'], tstate[i]['exp_avg_sq'], rtol=1e-5, atol=1e-9)
+            assert float(st[i]['step']) == 3.0
+
+
+def test_shard_plan_rejects_indivisible_world():
+    from distillclip_amd.parallel import _Shards
+    with pytest.raises(ValueError, match='not divisible'):
+        _Shards([(0, 64)], [[0, 64]], rank=0, world=3)
+    sh = _Shards(_BUCKETS, _TRAINABLE, rank=1, world=2)
+    assert sh.buckets[3] is None                                        # frozen-only bucket: never exchanged
+    b0, b1, o0, o1, off, own = sh.buckets[0]
+    assert (o0, o1) == (b0 + (b1 - b0) // 2, b1) and off == 0
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2 --dry-launch`: the parent starts two rank processes before touching any GPU and relays rank 0's
+    JSON line; a non-zero exit of a rank propagates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out == {'dry_launch': True, 'n_gpus': 2, 'backend': 'gloo'}
+    # a failing rank (WORLD_SIZE mismatch is impossible here, so ask for an unknown config) -> non-zero exit of the launcher
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch', '--config', 'nope'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from distillclip_amd.parallel import check_equal_batch
+    check_equal_batch(8, torch.device('cpu'))                 # equal: passes on every rank
+    try:
+        check_equal_batch(8 - rank, torch.device('cpu'))      # a loader without drop_last: last batch ragged
+        q.put((rank, 'no error'))
+    except ValueError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_negatives_reject_unequal_batches_on_every_rank():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=90) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all('same per-rank batch' in msg and '7..8' in msg for _, msg in res), res

@@ -74,6 +74,30 @@ def test_tiny_forward_vs_reference_golden(tiny):
         assert cosine(o.last_representation, ref) > 0.999, tag
 
 
+def test_tiny_last_layer_output_on_request_vs_reference_golden(tiny):
+    """`last_layer_output` [B, N, E] (reference output.py:16-35; _common.py:212-215, weight_share_model.py:364-366, :504-506) is
+    produced on request — by the ControlOutput extension flag or later from encoder.last_layer_output() — and its class / EOT
+    row is last_representation."""
+    from distillclip_amd.model.component import ControlOutput
+    s_img, s_txt, t_img, t_txt = _tiny_modules()
+    image, text = torch.from_numpy(tiny['image']).cuda(), torch.from_numpy(tiny['text']).cuda()
+    co = ControlOutput(need_last_layer_output=True)
+    outs = {'s_img': s_img(image, co), 's_txt': s_txt(text, co), 't_img': t_img(image, co), 't_txt': t_txt(text, co)}   # students in training mode
+    eot = text.argmax(-1)
+    for tag, o in outs.items():
+        ref = tiny[f'{tag}.last_layer_output']
+        assert tuple(o.last_layer_output.shape) == ref.shape
+        assert rel_l2(o.last_layer_output, ref) < 2e-2, (tag, rel_l2(o.last_layer_output, ref))
+        row = o.last_layer_output[:, 0] if 'img' in tag else o.last_layer_output[torch.arange(text.shape[0]), eot]
+        assert rel_l2(row, o.last_representation.detach().cpu().numpy()) < 1e-3, tag     # same LN + GEMM, all rows vs one row
+    with torch.no_grad():                       # inference-mode workspace layout + the explicit accessor
+        o = s_img(image)
+        assert o.last_layer_output is None
+        assert rel_l2(s_img.last_layer_output(), tiny['s_img.last_layer_output']) < 2e-2
+        t_txt(text)
+        assert rel_l2(t_txt.last_layer_output(), tiny['t_txt.last_layer_output']) < 2e-2
+
+
 def _grad_check(module, tiny, prefix, tol=5e-2, loose=2e-1):
     worst = {}
     for n, p in module.named_parameters():

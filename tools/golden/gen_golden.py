@@ -290,9 +290,95 @@ def real_shapes():
     print('real_b4.npz', len(out), 'arrays', 'loss', float(loss))
 
 
+def _train(student, teacher, s_img, s_txt, batches, lr, wd, warm, total, steps_per_epoch, tag, out):
+    """The reference's training loop arithmetic without the Lightning shell: dual_distill_model.py:120-127 (training_step:
+    student fwd, teacher fwd, LossCalculator) + what Lightning's automatic optimisation does around it (zero_grad, backward,
+    optimizer.step) + :194-202 (AdamW over filter(requires_grad, parameters()), HF cosine-with-warmup stepped per EPOCH)."""
+    from transformers.optimization import get_cosine_schedule_with_warmup
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})     # l_clip.yaml:29-32
+    opt = torch.optim.AdamW(filter(lambda p: p.requires_grad, student.parameters()), lr=lr, weight_decay=wd)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+    losses, lrs, terms = [], [], {}
+    for i, (image, text) in enumerate(batches):
+        so = student(text, image, lc.get_control_output())
+        to = teacher(text, image, lc.get_control_output())
+        loss, res = lc(so, to, 'all')
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        lrs.append(opt.param_groups[0]['lr'])
+        for k, v in res.items():
+            terms.setdefault(k, []).append(float(v))
+        if (i + 1) % steps_per_epoch == 0:
+            sched.step()
+    out[f'{tag}.loss'] = np.asarray(losses, dtype=np.float64)
+    out[f'{tag}.lr'] = np.asarray(lrs, dtype=np.float64)
+    for k, v in terms.items():
+        out[f'{tag}.term.{k}'] = np.asarray(v, dtype=np.float64)
+    out[f'{tag}.s_img.last_representation'] = np_(so.visual_output.last_representation)
+    out[f'{tag}.s_txt.last_representation'] = np_(so.text_output.last_representation)
+    return opt
+
+
+def trajectory():
+    """the l_clip plumbing run — B = 4, 16 steps over 64 synthetic pairs — as a loss TRAJECTORY of the
+    reference with its optimizer and per-epoch schedule (tiny config: all 16 steps = 4 epochs of 4; real shapes: 4 steps).
+    Pins forward + backward + AdamW + schedule end to end.  Inputs are synth.images / synth.captions of the stored seed."""
+    out = {}
+    # ---- tiny: 16 steps, 4 epochs x 4 batches, warm-up 2 epochs (epoch 0 runs at lr 0: HF's multiplier is 0 / warm) -------
+    c = TINY
+    seed, B, n = 31, 4, 64
+    images = torch.from_numpy(synth.images(seed, n, c['res']))
+    texts = torch.from_numpy(synth.captions(seed, n, c['ctx'], c['vocab'], 3, 9))
+    t_img = build_teacher_image(seed, c['t_img']['width'], c['t_img']['layers'], c['patch'], c['res'], c['out_dim'])
+    t_txt = build_teacher_text(seed, c['t_txt']['width'], c['t_txt']['layers'], c['ctx'], c['vocab'], c['out_dim'])
+    s_img, s_txt = build_student_image(seed, **c['s_img']), build_student_text(seed, **c['s_txt'])
+    student, teacher = CLIPModel(True, s_img, s_txt, False), CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    batches = [(images[i:i + B], texts[i:i + B]) for i in range(0, n, B)]
+    out.update({'tiny.seed': np.int64(seed), 'tiny.B': np.int64(B), 'tiny.steps': np.int64(len(batches)), 'tiny.lr': np.float64(2e-3),
+                'tiny.wd': np.float64(1e-2), 'tiny.warm': np.int64(2), 'tiny.total': np.int64(8), 'tiny.steps_per_epoch': np.int64(4)})
+    base_lr = 2e-3
+    opt = _train(student, teacher, s_img, s_txt, batches, base_lr, 1e-2, 2, 8, 4, 'tiny', out)
+    out['tiny.base_lr'] = np.float64(base_lr)
+    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+        for name, p in m.named_parameters():
+            out[f'tiny.{tag}.final.{name}'] = np_(p)
+    # ---- real shapes: ViT-B/32 teacher + the shipped l_clip students, 4 steps at B = 4, l_clip.yaml's lr / wd, constant lr --------
+    seed, B, n = 2023, 4, 16
+    images = torch.from_numpy(synth.images(seed, n, 224))
+    texts = torch.from_numpy(synth.captions(seed, n))
+    t_img, t_txt = build_teacher_image(seed, 768, 12, 32, 224, 512), build_teacher_text(seed, 512, 12, 77, 49408, 512)
+    s_img_cfg = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                     mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    s_img, s_txt = build_student_image(seed, **s_img_cfg), build_student_text(seed, **s_txt_cfg)
+    before = {('s_img', k): v.detach().clone() for k, v in s_img.named_parameters()}
+    before.update({('s_txt', k): v.detach().clone() for k, v in s_txt.named_parameters()})
+    student, teacher = CLIPModel(True, s_img, s_txt, False), CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    batches = [(images[i:i + B], texts[i:i + B]) for i in range(0, n, B)]
+    out.update({'real.seed': np.int64(seed), 'real.B': np.int64(B), 'real.steps': np.int64(len(batches)),
+                'real.base_lr': np.float64(1e-3), 'real.wd': np.float64(1e-3)})
+    _train(student, teacher, s_img, s_txt, batches, 1e-3, 1e-3, 0, 300, 10 ** 9, 'real', out)
+    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+        for name, p in m.named_parameters():
+            d = p.detach() - before[(tag, name)]
+            out[f'real.{tag}.dnorm.{name}'] = np_(d.norm())            # how far 4 AdamW steps moved every parameter
+        for name in ('head.weight', 'blocks.0.block.attn.qkv.weight', 'blocks.1.block.mlp.fc2.weight', 'norm.weight'):
+            out[f'real.{tag}.final_slice.{name}'] = np_(dict(m.named_parameters())[name].reshape(-1)[:256])
+    np.savez_compressed(os.path.join(OUT, 'trajectory.npz'), **out)
+    print('trajectory.npz', len(out), 'arrays; tiny losses', np.round(out['tiny.loss'], 5), 'real losses', np.round(out['real.loss'], 5))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tiny', 'loss', 'real']
+    which = sys.argv[1:] or ['tiny', 'loss', 'real', 'trajectory']
+    if 'trajectory' in which:
+        trajectory()
     if 'tiny' in which:
         tiny_dual()
     if 'loss' in which:
