@@ -104,6 +104,35 @@ def make_inputs(wl, seed, B):
     return image, text, caps
 
 
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a share of
+    the host: os.cpu_count() reports the whole machine and oversubscribing it makes the torch CPU path slower, not faster)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -122,7 +151,7 @@ def cpu_baseline(wl, seed, budget_s=40.0):
     import torch
     import oracle
     from distillclip_amd import synth
-    ncpu = os.cpu_count() or 1
+    ncpu = effective_cpus()
     kind = wl['kind']
     res = wl['res']
     cfg_i = dict(S_IMG, img_size=res)
@@ -178,14 +207,17 @@ def cpu_baseline(wl, seed, budget_s=40.0):
             break
         torch.set_num_threads(nt)
         step = make_step(B)
+        log(f'cpu baseline: batch {B}, {nt} threads ...')
+        t0 = time.perf_counter()
         step()                                      # warm-up
+        t_warm = time.perf_counter() - t0
         times = []
         for _ in range(3):
+            if times and time.perf_counter() - t_start + t_warm > 2.0 * budget_s:
+                break                               # slow host: fewer than 3 timed steps, said so in `sample`
             t0 = time.perf_counter()
             step()
             times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > 2.0 * budget_s:
-                break
         rate = B / min(times)
         tried.append({'batch': B, 'threads': nt, 'best_step_s': round(min(times), 4), 'steps_timed': len(times),
                       f'{wl["unit"]}_per_s': round(rate, 3)})
@@ -194,7 +226,7 @@ def cpu_baseline(wl, seed, budget_s=40.0):
     torch.set_num_threads(ncpu)
     rate, B, nt, n = best
     return {'value': round(rate, 3), 'unit': f'{wl["unit"]}/s', 'cores': nt, 'kind': 'port', 'cpu_model': cpu_model_name(),
-            'host_logical_cpus': ncpu,
+            'usable_cpus': ncpu, 'host_logical_cpus': os.cpu_count(),
             'sample': f'best of {n} timed steps (after 1 warm-up) of the same {wl["kind"]} distill step at batch {B}, fp32 torch CPU, '
                       f'{nt} threads; sweep over batch {{32, 4}} x threads {threads} bounded to ~{int(budget_s)} s',
             'sweep': tried}
@@ -273,6 +305,12 @@ def main():
     if args.dry_launch:
         return dry_launch()
 
+    # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner at communicator creation does)
+    # are sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get('RANK', '0'))
@@ -340,9 +378,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    log(f'{args.config}: model built, batch {B} / GPU, world {world}; warm-up')
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    log('timed steps')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -353,6 +393,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+    log(f'{args.steps} steps in {dt:.3f} s; loss {final_loss:.5f}')
 
     roofline = None
     if not args.no_roofline:
@@ -412,6 +453,7 @@ def main():
                                for k, v in agg.items()}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('roofline probe done; CPU baseline')
         cpu = cpu_baseline(wl, seed)
 
     if rank == 0:
@@ -436,7 +478,8 @@ def main():
             out['roofline'] = roofline
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -195,6 +195,28 @@ class HipTower:
                                     torch.cuda.current_stream().cuda_stream)
         self.wcache_dirty = False
 
+    def _bind_image_size(self, x):
+        """The patch conv floors (reference _common.py:176,196 / timm PatchEmbed: Conv2d(k=p, s=p) on a 336 px image with p = 32
+        reads the top-left 320 x 320): the plan's `resolution` is the row stride of the INPUT, which a teacher built from a
+        checkpoint only knows as patch * grid (utils.py:18-28 -> 320 for a [101, 768] positional table).  Re-plan (host-side,
+        same token count, same buffers) when the images are larger than that; anything that changes the grid is an error."""
+        if x.dim() != 4 or x.shape[1] != self.cfg.in_chans or x.shape[2] != x.shape[3]:
+            raise ValueError(f'image tower expects [B, {self.cfg.in_chans}, R, R] inputs, got {tuple(x.shape)}')
+        res = int(x.shape[-1])
+        if res == self.cfg.resolution:
+            return
+        grid = res // self.cfg.patch
+        if grid * grid + 1 != self.cfg.tokens:
+            raise ValueError(f'{res} px images give {grid * grid + 1} tokens at patch {self.cfg.patch}; this tower has '
+                             f'{self.cfg.tokens} (positional table)')
+        cfg = EncoderCfg.from_buffer_copy(self.cfg)
+        cfg.resolution = res
+        handle = lib().dclip_encoder_create(ctypes.byref(cfg))
+        if not handle:
+            raise ValueError(lib().dclip_last_error_string().decode())
+        lib().dclip_encoder_destroy(self._handle)
+        self._handle, self.cfg = handle, cfg
+
     # ---- execution -----------------------------------------------------------------------------------------------
     def forward(self, x, training, need_rep=False, need_emb=False, rep_layers=None, tokens_eff=0):
         """-> (last_representation [B,E], input as passed to C, hidden states list, embedding or None)"""
@@ -204,6 +226,8 @@ class HipTower:
         if x.dtype != expect:
             x = x.to(expect)
         x = x.contiguous()
+        if self.cfg.modality == 0:
+            self._bind_image_size(x)
         self.materialize(x.device)
         ev = getattr(self, 'opt_done', None)
         if ev is not None:                         # an optimizer update of these weights may still be running on another stream

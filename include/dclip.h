@@ -281,7 +281,8 @@ typedef struct dclip_encoder_cfg {
     int32_t repeats;     /* repeated_times (teacher: 1) */
     int32_t mlp_dim;     /* int(D * mlp_ratio) */
     int32_t out_dim;     /* E */
-    int32_t patch, resolution, in_chans;  /* image only */
+    int32_t patch, resolution, in_chans;  /* image only; resolution = height = width of the INPUT images; the patch conv floors
+                                           * (grid = resolution / patch: 336 px at patch 32 reads the top-left 320 x 320) */
     int32_t vocab, embed_rank;            /* text only; embed_rank = embedding_compression_dim or 0 */
     int32_t head_mix;    /* use_transform: conv_l / conv_w cross-head mixing */
     int32_t causal;      /* teacher text: 1 */

@@ -346,5 +346,7 @@ def test_reduce_scatter_sharded_path_over_rccl_world1_equals_plain_path():
     finally:
         dist.destroy_process_group()
     for k in plain:
-        # wgrad atomics are not bit-reproducible between runs: same tolerance as the resume test
-        assert torch.allclose(plain[k], sharded[k], rtol=2e-3, atol=2e-5), (k, (plain[k] - sharded[k]).abs().max())
+        # wgrad atomics are not bit-reproducible between runs and Adam's m / sqrt(v) turns a rounding-level gradient
+        # difference into up to +-lr per step on near-zero-gradient elements: 3 steps at lr 1e-3
+        d = (plain[k] - sharded[k]).abs()
+        assert d.max() < 3e-3 and d.mean() < 2e-5, (k, d.max().item(), d.mean().item())

@@ -68,9 +68,9 @@ def test_tiny_16_step_loss_trajectory_vs_reference(traj):
     err = np.abs(np.asarray(losses) - ref) / np.abs(ref)
     print('tiny trajectory rel err per step', np.round(err, 4))
     # the first epoch runs at lr 0 (4 different batches, initial weights): pure forward parity
-    assert err[:4].max() < 2e-2, err[:4]
+    assert err[:4].max() < 5e-3, err[:4]              # measured <= 7e-4
     # 12 AdamW steps later the bf16 path still follows the fp32 reference (errors compound through the weights)
-    assert err.max() < 5e-2, err
+    assert err.max() < 2e-2, err                      # measured <= 4e-3
     assert losses[-1] < 0.5 * losses[0]                                              # and it trains: 0.74 -> 0.26 in the reference
     # final weights: relative L2 of what training moved (delta from the initial weights) for the large tensors
     init = {'s_img': T(synth.student_image_state(seed, **c['s_img'])), 's_txt': T(synth.student_text_state(seed, **c['s_txt']))}
@@ -103,7 +103,7 @@ def test_real_shapes_4_step_loss_trajectory_vs_reference(traj):
     ref = traj['real.loss']
     err = np.abs(np.asarray(losses) - ref) / np.abs(ref)
     print('real trajectory', np.round(losses, 5), 'ref', np.round(ref, 5), 'rel err', np.round(err, 4))
-    assert err[0] < 2e-2 and err.max() < 5e-2, err
+    assert err[0] < 5e-3 and err.max() < 2e-2, err     # measured 3e-4 / 5e-3
     # how far 4 AdamW steps moved every parameter (norm of the delta): the optimizer's arithmetic at real shapes
     init = {'s_img': T(synth.student_image_state(seed, **cfg_i)), 's_txt': T(synth.student_text_state(seed, **cfg_t))}
     worst = {}
@@ -112,5 +112,6 @@ def test_real_shapes_4_step_loss_trajectory_vs_reference(traj):
             d = (p.detach().cpu() - init[tag][name]).norm().item()
             want = float(traj[f'real.{tag}.dnorm.{name}'])
             worst[f'{tag}.{name}'] = abs(d - want) / (want + 1e-12)
-    bad = {k: v for k, v in worst.items() if v > 0.1}
+    # (the k-part of attn.qkv.bias has a zero true gradient: Adam normalises rounding noise there, run-dependent direction)
+    bad = {k: v for k, v in worst.items() if v > (0.35 if 'qkv.bias' in k else 0.1)}
     assert not bad, bad
