@@ -1091,6 +1091,7 @@ extern "C" int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t
     AttnMM p{A, lda, (const bf16_t*)Bm, ldb, C, Np, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
     if (int rc = check_mm(p, "dclip_attn_nt")) return rc;
     DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "dclip_attn_nt: token-major strides must be multiples of 8");
+    TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + (out_f32 ? 4.0 : 2.0) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 1);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (hd == 32) {
@@ -1107,6 +1108,7 @@ extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C
                              int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
     AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
     if (int rc = check_mm(p, "dclip_attn_nn")) return rc;
+    TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 2);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (hd == 32) hipLaunchKernelGGL((attn_nn_kernel<32>), grid, dim3(256), 4 * NMAX * (32 * 2 + 32), st, p);
@@ -1118,6 +1120,7 @@ extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C
                              int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
     AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
     if (int rc = check_mm(p, "dclip_attn_tn")) return rc;
+    TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 3);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (hd == 32) hipLaunchKernelGGL((attn_tn_kernel<32>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (32 * 2 + 32)), st, p);
@@ -1131,6 +1134,7 @@ extern "C" int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int
     DCLIP_REQUIRE(hd == 32 || hd == 64, "dclip_attn_fused_fwd: head dim must be 32 or 64 (got %ld)", (long)hd);
     DCLIP_REQUIRE(ldq % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 8) == 0, "dclip_attn_fused_fwd: misaligned buffers");
     AttnFused p{(const bf16_t*)qkv, ldq, (bf16_t*)ctx, ldc, (int)B, (int)H, (int)N, causal, scale};
+    TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd, 8.0 * B * H * N * hd, stream, (int)(B * H), (int)N, (int)hd, 4);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     const int n32 = ((int)N + 31) & ~31;
     const size_t lds = (size_t)4 * (n32 * (hd * 2 + 32) + 16 * (n32 * 2 + 16));
@@ -1158,6 +1162,7 @@ extern "C" int dclip_attn_softmax_fwd(const float* S, const float* Wl, const flo
     DCLIP_REQUIRE(S && R && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_softmax_fwd: bad argument");
     DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_fwd: conv_l and conv_w come together");
     SoftmaxFwd p{S, Wl, Ww, (bf16_t*)P, (bf16_t*)R, (int)B, (int)N, (int)Np, causal};
+    TraceScope tr(DCLIP_TRACE_ATTN, Wl ? 4.0 * B * H * H * N * N : 0.0, (4.0 + 2.0 + (P ? 2.0 : 0.0)) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)H, 5);
     const int ns = N > 64 ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
     static const int mfma_mode = [] { const char* e = getenv("DCLIP_SOFTMAX_MFMA"); return e ? atoi(e) : 1; }();
@@ -1206,6 +1211,7 @@ extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const void*
     DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_bwd: conv_l and conv_w come together");
     DCLIP_REQUIRE(!Wl || S, "dclip_attn_softmax_bwd: raw scores needed for dW_l");
     SoftmaxBwd p{(const bf16_t*)dR, (const bf16_t*)P, (const float*)S, scores_bf16, Wl, Ww, (bf16_t*)dS, dWl, dWw, (int)B, (int)N, (int)Np};
+    TraceScope tr(DCLIP_TRACE_ATTN, Wl ? 8.0 * B * H * H * N * N : 0.0, (2.0 + 2.0 + 2.0 + (Wl ? (scores_bf16 ? 2.0 : 4.0) : 0.0)) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)H, 6);
     int blocks = (int)((B * N + 3) / 4);
     if (blocks > 2048) blocks = 2048;
     const int ns = N > 64 ? 2 : 1;

@@ -23,18 +23,19 @@ extern "C" const char* dclip_last_error_string(void) { return g_err; }
 #include <vector>
 
 namespace {
-struct TraceRec { hipEvent_t a, b; int kind; double flops; double bytes; };
+struct TraceRec { hipEvent_t a, b; int kind; double flops; double bytes; int dims[4]; };
 std::mutex g_trace_mu;
 bool g_trace_on = false;
 std::vector<TraceRec> g_trace;
 size_t g_trace_cap = 0;
 }  // namespace
 
-bool dclip_trace_open(int kind, double flops, double bytes, void* stream, int* slot) {
+bool dclip_trace_open(int kind, double flops, double bytes, void* stream, int* slot, int d0, int d1, int d2, int d3) {
     std::lock_guard<std::mutex> lk(g_trace_mu);
     if (!g_trace_on || g_trace.size() >= g_trace_cap) return false;
     TraceRec r;
     r.kind = kind; r.flops = flops; r.bytes = bytes;
+    r.dims[0] = d0; r.dims[1] = d1; r.dims[2] = d2; r.dims[3] = d3;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
     (void)hipEventRecord(r.a, (hipStream_t)stream);
     g_trace.push_back(r);
@@ -71,5 +72,17 @@ extern "C" int64_t dclip_trace_end(int32_t* kind, float* ms, double* flops, doub
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_trace.clear();
+    return n;
+}
+
+// the problem sizes of the traced calls (4 ints per record: GEMM M, N, K, variant; other kinds rows, width, 0, 0); call BEFORE
+// dclip_trace_end, which consumes the records
+extern "C" int64_t dclip_trace_dims(int32_t* dims, int64_t cap) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    int64_t n = 0;
+    for (auto& r : g_trace) {
+        if (n < cap) for (int i = 0; i < 4; ++i) dims[n * 4 + i] = r.dims[i];
+        ++n;
+    }
     return n;
 }

@@ -26,11 +26,13 @@ void dclip_set_error(const char* fmt, ...);
     } while (0)
 
 // launch trace (capi.cpp): open() returns false unless dclip_trace_begin() enabled tracing
-bool dclip_trace_open(int kind, double flops, double bytes, void* stream, int* slot);
+bool dclip_trace_open(int kind, double flops, double bytes, void* stream, int* slot, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0);
 void dclip_trace_close(int slot, void* stream);
 struct TraceScope {
     int slot = -1; void* st;
-    TraceScope(int kind, double flops, double bytes, void* stream) : st(stream) { if (!dclip_trace_open(kind, flops, bytes, stream, &slot)) slot = -1; }
+    TraceScope(int kind, double flops, double bytes, void* stream, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0) : st(stream) {
+        if (!dclip_trace_open(kind, flops, bytes, stream, &slot, d0, d1, d2, d3)) slot = -1;
+    }
     ~TraceScope() { if (slot >= 0) dclip_trace_close(slot, st); }
 };
 #define DCLIP_TRACE_GEMM_NT 0
@@ -38,6 +40,7 @@ struct TraceScope {
 #define DCLIP_TRACE_LAYERNORM 2
 #define DCLIP_TRACE_LOSS 3
 #define DCLIP_TRACE_ATTN 4
+#define DCLIP_TRACE_LN_BWD 5
 
 static inline int dclip_check_launch(const char* what) {
     hipError_t e = hipGetLastError();

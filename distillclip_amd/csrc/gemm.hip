@@ -1035,7 +1035,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.preload = epi_preload;
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
-                  2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream);
+                  2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream, (int)M, (int)N, (int)K,
+                  act + 8 * (out_f32 != 0) + 16 * (residual != nullptr) + 32 * (colsum_acc != nullptr));
     switch (act) {
         case 0: return launch_nt<0>(p, out_f32 != 0, st);
         case 1: return launch_nt<1>(p, out_f32 != 0, st);
@@ -1079,11 +1080,11 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
         ch = ((ch + TC - 1) / TC) * TC;
         q.chunk = ch;
         q.splits = (int)((M + ch - 1) / ch);
-        TraceScope tr2(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
+        TraceScope tr2(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream, (int)M, (int)P, (int)Q, 256);
         hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 8 * HT, (hipStream_t)stream, q);
         return dclip_check_launch("dclip_gemm_tn_acc");
     }
-    TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream);
+    TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream, (int)M, (int)P, (int)Q, 128);
     if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), TN_LDS, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 4 * TTILE, (hipStream_t)stream, p);
     return dclip_check_launch("dclip_gemm_tn_acc");

@@ -192,6 +192,8 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
     const int nv = (int)((D + 255) / 256);
     int blocks = (int)((M + 3) / 4);
     if (blocks > 1024) blocks = 1024;
+    // algorithmic bytes: read dy (2 or 4), x (4), dx_acc (4) ; write dx_acc (4) + optional bf16 copy (2)
+    TraceScope tr(DCLIP_TRACE_LN_BWD, 12.0 * (double)M * D, (double)M * D * ((dy_f32 ? 4.0 : 2.0) + 12.0 + (dx_bf16 ? 2.0 : 0.0)), stream, (int)M, (int)D, 0, 0);
     hipStream_t st = (hipStream_t)stream;
     LN_DISPATCH(nv,
         if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D);

@@ -332,9 +332,12 @@ int dclip_encoder_grad_bucket(const dclip_encoder* enc, int32_t bucket, int32_t*
 /* ---------------------------------------------------------------------------------------------------------------
  * Launch trace (profiling only; process-global): between begin and end every GEMM / LayerNorm-forward / loss call is
  * bracketed by HIP events on the stream it is launched on.  trace_end writes (kind, ms, algorithmic flops, algorithmic
- * bytes) per call and returns the number of calls seen.  kind: 0 gemm_nt, 1 gemm_tn_acc, 2 layernorm_fwd, 3 distill_loss. */
+ * bytes) per call and returns the number of calls seen.  kind: 0 gemm_nt, 1 gemm_tn_acc, 2 layernorm_fwd, 3 distill_loss,
+ * 4 attention family (nt / nn / tn / fused / softmax fwd / softmax bwd), 5 layernorm_bwd. */
 int dclip_trace_begin(int64_t max_records);
 int64_t dclip_trace_end(int32_t* kind, float* ms, double* flops, double* bytes, int64_t cap);
+/* problem sizes of the traced calls so far, 4 ints per record (GEMM: M, N, K, variant bits); call before dclip_trace_end */
+int64_t dclip_trace_dims(int32_t* dims, int64_t cap);
 
 #ifdef __cplusplus
 }

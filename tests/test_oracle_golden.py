@@ -288,3 +288,28 @@ def test_real_shapes_4_step_trajectory_matches_reference(traj):
     batches = [(images[i:i + B], texts[i:i + B]) for i in range(0, n, B)]
     losses = _oracle_train(sd_i, sd_t, t_i, t_t, 24, 12, batches, float(traj['real.base_lr']), float(traj['real.wd']), 0, 300, 10 ** 9)
     np.testing.assert_allclose(losses, traj['real.loss'], rtol=5e-4)
+
+
+def test_bf16_matched_mode_stays_within_bf16_noise_of_the_pinned_oracle(tiny, tiny_models):
+    """oracle.bf16_matched() only inserts bf16 round-trips at the HIP path's storage points (oracle/encoders.py header): the
+    arithmetic between them is the pinned restatement's, so values and gradients stay within bf16 noise of the fp32 goldens."""
+    image, text = torch.from_numpy(tiny['image']), torch.from_numpy(tiny['text'])
+    m = {k: {n: v.detach().clone().requires_grad_(v.requires_grad) for n, v in sd.items()} for k, sd in tiny_models.items()}
+    lc = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})
+    with oracle.bf16_matched():
+        so = oracle.clip_forward(oracle.student_image_forward(m['s_img'], image, 4), oracle.student_text_forward(m['s_txt'], text, 2))
+        with torch.no_grad():
+            to = oracle.clip_forward(oracle.teacher_image_forward(m['t_img'], image), oracle.teacher_text_forward(m['t_txt'], text))
+        loss, _ = lc(so, to, 'all')
+        loss.backward()
+    for tag, o in (('s_img', so['visual_output']), ('s_txt', so['text_output']), ('t_img', to['visual_output']), ('t_txt', to['text_output'])):
+        ref = tiny[f'{tag}.last_representation']
+        e = np.linalg.norm(o['last_representation'].detach().numpy() - ref) / np.linalg.norm(ref)
+        assert 1e-5 < e < 2e-2, (tag, e)                     # it DOES round (e > 0) and stays at bf16 level
+    assert abs(loss.item() - float(tiny['lclip.loss'])) < 2e-2 * float(tiny['lclip.loss'])
+    g = m['s_img']['head.weight'].grad.numpy()
+    ref = tiny['lclip.s_img.grad.head.weight']
+    assert np.linalg.norm(g - ref) / np.linalg.norm(ref) < 2e-1
+    # and the mode is scoped: outside the context the restatement is exact fp32 again
+    out = oracle.student_image_forward(tiny_models['s_img'], image, 4)
+    close(out['last_representation'], tiny['s_img.last_representation'])

@@ -175,6 +175,55 @@ def test_tiny_backward_smooth_loss_vs_oracle(tiny):
         assert not bad, bad
 
 
+def test_tiny_backward_vs_rounding_matched_oracle(tiny):
+    """End-to-end gradient parity held TIGHT: the oracle in bf16_matched() mode rounds to bf16 at the same storage points as the
+    HIP path (oracle/encoders.py header), so what is left is accumulation order — every parameter gradient, incl. the conv_l /
+    conv_w head mixes, biases and LayerNorm affine parameters, agrees to ~1e-2 where the fp32 oracle allows only ~1e-1.  A backward
+    error of a few per cent in any kernel fails here."""
+    from distillclip_amd.model import LossCalculator
+    from distillclip_amd.model.component import CLIPModel
+    c = TINY
+    s_img, s_txt, t_img, t_txt = _tiny_modules()
+    student, teacher = CLIPModel(True, s_img, s_txt), CLIPModel(False, t_img, t_txt)
+    image, text = torch.from_numpy(tiny['image']), torch.from_numpy(tiny['text'])
+    lc = LossCalculator(['out_cos', 'out_kl', 'soft_label'], temperature=1.5)
+    so_h = student(text.cuda(), image.cuda())
+    loss, _ = lc(so_h, teacher(text.cuda(), image.cuda()), 'all')
+    loss.backward()
+    sd_i = {k: v.clone().requires_grad_(True) for k, v in T(synth.student_image_state(c['seed'], **c['s_img'])).items()}
+    sd_t = {k: v.clone().requires_grad_(True) for k, v in T(synth.student_text_state(c['seed'], **c['s_txt'])).items()}
+    with oracle.bf16_matched():
+        with torch.no_grad():
+            ti = oracle.teacher_image_forward(T(synth.teacher_image_state(c['seed'], 128, 2, c['patch'], c['res'], c['out_dim'])), image)
+            tt = oracle.teacher_text_forward(T(synth.teacher_text_state(c['seed'], 128, 2, c['ctx'], c['vocab'], c['out_dim'])), text)
+        so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, 4), oracle.student_text_forward(sd_t, text, 2))
+        ol, _ = oracle.LossOracle(['out_cos', 'out_kl', 'soft_label'], temperature=1.5)(so, oracle.clip_forward(ti, tt), 'all')
+        ol.backward()
+    e_emb = {'s_img': rel_l2(so_h.visual_output.last_representation, so['visual_output']['last_representation'].detach().numpy()),
+             's_txt': rel_l2(so_h.text_output.last_representation, so['text_output']['last_representation'].detach().numpy())}
+    errs = {}
+    for tag, mod, sd in (('s_img', s_img, sd_i), ('s_txt', s_txt, sd_t)):
+        for n, p in mod.named_parameters():
+            if sd[n].grad is not None and sd[n].grad.abs().max() > 0:
+                errs[f'{tag}.{n}'] = rel_l2(p.grad, sd[n].grad.numpy())
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print('matched-oracle parity: loss', abs(loss.item() - ol.item()) / abs(ol.item()), 'embeddings', e_emb, 'worst gradients', top)
+    assert abs(loss.item() - ol.item()) <= 2e-3 * abs(ol.item())
+    assert max(e_emb.values()) < 5e-3, e_emb
+    # the k-third of attn.qkv.bias has a zero true gradient (softmax shift invariance): pure rounding noise, compared on q / v only
+    bad = {}
+    for n, e in errs.items():
+        if n.endswith('attn.qkv.bias'):
+            tag, name = n.split('.', 1)
+            mod, sd = (s_img, sd_i) if tag == 's_img' else (s_txt, sd_t)
+            g, r = dict(mod.named_parameters())[name].grad.detach().cpu(), sd[name].grad
+            D = g.numel() // 3
+            e = max(rel_l2(g[:D], r[:D].numpy()), rel_l2(g[2 * D:], r[2 * D:].numpy()))
+        if e > 2.5e-2:                    # measured <= 1.5e-2 (fp32 oracle: 8e-2 / 1.5e-1 in the test above)
+            bad[n] = e
+    assert not bad, bad
+
+
 def test_tiny_one_tower_text_compressed(tiny):
     from distillclip_amd.model import LossCalculator
     from distillclip_amd.model.component import RepeatTextTransformer
