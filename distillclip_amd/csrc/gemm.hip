@@ -253,6 +253,22 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int64_t
     __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(buf + (wave * 2 + 1) * SUB), 16, 0, 0);
 }
 
+// 160-row half-tile (the 320-row tile variant): row blocks 0-7 as above, plus the four [16 x 32] sub-tiles of row blocks 8 and 9,
+// one per wave (waves 4-7 repeat what waves 0-3 load: identical bytes to identical LDS addresses, so that every wave issues the
+// same number of LDS-DMA instructions and the counted vmcnt waits stay wave-independent)
+__device__ __forceinline__ void stage_half160(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max, int k0,
+                                              char* buf, int wave, int lane) {
+    stage_half(G, ld, row0, rows_max, k0, buf, wave, lane);
+    const int L = lane * 16;
+    const int X = swz(L);
+    const int r = X >> 6, c = (X >> 4) & 3;
+    const int e = wave & 3, rb = 8 + (e >> 1), kb = e & 1;
+    int row = row0 + rb * 16 + r;
+    row = row < rows_max ? row : rows_max - 1;
+    const bf16_t* src = G + (int64_t)row * ld + k0 + kb * 32 + c * 8;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (rb * 2 + kb) * SUB), 16, 0, 0);
+}
+
 // side operands of one output row segment, loaded ahead of use: residual and C may alias (in-place residual stream), so the
 // compiler cannot hoist these loads above the previous row's store by itself — left inside the row loop every row pays a
 // full HBM round trip in sequence
@@ -348,9 +364,17 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, const float* crow
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int ACT, bool OUT_F32>
+// MI = 16-row MFMA tiles per wave along M: 8 -> the 256 x 256 tile, 10 -> a 320 x 256 tile.  The taller tile exists for wave
+// quantisation: a [25600, 768] output is 300 tiles of 256^2 (two rounds on 256 CUs, the second 17 % full) but 240 tiles of
+// 320 x 256 (one round); [39424, 512] is 308 against 248.  launch_nt picks the variant with the smaller rounds x tile-work.
+template <int ACT, bool OUT_F32, int MI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RH = MI / 2;                      // row tiles per phase
+    constexpr int AROWS = MI * 16;                  // rows of an A half-tile (one wave group's rows)
+    constexpr int HTA = AROWS * BK * 2;             // bytes of an A half-tile
+    constexpr int PAR = 2 * HT + 2 * HTA;           // one parity: B_lo, B_hi, A_lo, A_hi
+    constexpr int BMT = 2 * AROWS;                  // tile rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -358,47 +382,48 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int tm = t / p.tiles_n, tn = t % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * BMT, n0 = tn * 256;
     const int nk = p.K / BK;
     const int nload = 4 * nk;
 
-    f32x4 acc[8][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_lo, 3 A_hi ; LDS slot (tile & 1) * 4 + w
+    // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_lo, 3 A_hi
     auto issue = [&](int l) {
         const int tile = l >> 2, w = l & 3;
-        char* buf = smem + ((tile & 1) * 4 + w) * HT;
-        if (w < 2) stage_half(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, buf, wave, lane);
-        else stage_half(p.A, p.lda, m0 + (w - 2) * 128, p.M, tile * BK, buf, wave, lane);
+        char* par = smem + (tile & 1) * PAR;
+        if (w < 2) stage_half(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, lane);
+        else if (MI == 8) stage_half(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
+        else stage_half160(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
     };
     const int npro = nload < 5 ? nload : 5;
     for (int l = 0; l < npro; ++l) issue(l);
-    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);
+    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);      // the youngest half-tile in flight is always a B half: 2 instructions
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
 
     const int fragoff = swz((lane & 15) * 64 + (lane >> 4) * 16);
-    const int a_off = (2 + wr) * HT;                         // this wave's A half
+    const int a_off = 2 * HT + wr * HTA;                     // this wave's A half
     const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    bf16x8 af[RH][2], b0[2][2], b1[2][2];
 
     for (int kt = 0; kt < nk; ++kt) {
-        const char* base = smem + (kt & 1) * 4 * HT;
+        const char* base = smem + (kt & 1) * PAR;
         const char* ap = base + a_off + fragoff;
         const char* bp = base + b_off + fragoff;
         const int k4 = kt * 4;
-        // ---------------- phase 0 : quadrant (rows 0-63, cols 0-31) ----------------
+        // ---------------- phase 0 : quadrant (upper rows, cols 0-31) ----------------
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) b0[j][kb] = *(const bf16x8*)(bp + (j * 2 + kb) * SUB);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RH; ++i)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + (i * 2 + kb) * SUB);
         if (k4 + 5 < nload) issue(k4 + 5);
@@ -408,13 +433,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
-        // ---------------- phase 1 : quadrant (rows 0-63, cols 32-63) ----------------
+        // ---------------- phase 1 : quadrant (upper rows, cols 32-63) ----------------
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -426,17 +451,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
-        // ---------------- phase 2 : quadrant (rows 64-127, cols 32-63) ----------------
+        // ---------------- phase 2 : quadrant (lower rows, cols 32-63) ----------------
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RH; ++i)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + ((4 + i) * 2 + kb) * SUB);
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + ((RH + i) * 2 + kb) * SUB);
         if (k4 + 7 < nload) issue(k4 + 7);
         __builtin_amdgcn_s_barrier();
         WAIT_LGKM0();
@@ -444,13 +469,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[4 + i][2 + j], 0, 0, 0);
+                    acc[RH + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[RH + i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
-        // ---------------- phase 3 : quadrant (rows 64-127, cols 0-31) ----------------
+        // ---------------- phase 3 : quadrant (lower rows, cols 0-31) ----------------
         if (k4 + 8 < nload) { issue(k4 + 8); WAIT_VMCNT(2); }
         else WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
@@ -458,16 +483,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[4 + i][j], 0, 0, 0);
+                    acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[RH + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
 
-    // epilogue: 4 slabs of 64 rows (32 rows of each wave group) staged through LDS, row-contiguous 8-wide vectors
+    // epilogue: RH slabs of 64 rows (32 rows of each wave group) staged through LDS, row-contiguous 8-wide vectors
     float* cs = (float*)smem;
     const int cc = (tid & 31) * 8;
     const int col = n0 + cc;
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < RH; ++q) {
         // this slab's residual / aux rows start their HBM round trip before the accumulators go through LDS (only in the
         // variants that have such operands: the others lose registers and time to it)
         constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
@@ -492,12 +517,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int sl = (tid >> 5) + it * 16;
-                const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+                const int row = m0 + (sl >> 5) * AROWS + q * 32 + (sl & 31);
                 if (row < p.M) epilogue_load_side<ACT>(p, row, col, side[it]);
             }
         }
         __syncthreads();
-        // slab row = wr * 32 + (0..31)  <->  tile row wr * 128 + q * 32 + (0..31)
+        // slab row = wr * 32 + (0..31)  <->  tile row wr * AROWS + q * 32 + (0..31)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int sl = (tid >> 5) + it * 16;                     // slab row 0..63
-                const int row = m0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+                const int row = m0 + (sl >> 5) * AROWS + q * 32 + (sl & 31);
                 if (row < p.M) epilogue_vec8<ACT, OUT_F32>(p, cs + sl * CLD2 + cc, row, col, bias, csum, pre ? &side[it] : nullptr);
             }
         }
@@ -992,11 +1017,32 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
                 tm = tm1;
             }
         }
+        // tile height: 256 or 320 rows, whichever needs fewer rounds x rows on 256 CUs (a tie keeps the 256-row tile, whose
+        // loads carry no duplicates); DCLIP_GEMM320=0 disables the 320-row variant, =2 forces it
+        static const int mode320 = [] { const char* e = getenv("DCLIP_GEMM320"); return e ? atoi(e) : 1; }();
+        bool tall = false;
+        // (the DGELU / MULAUX epilogues keep side operands in registers ahead of the LDS staging: with 160 accumulator registers
+        //  that spills, so those variants stay on the 256-row tile)
+        constexpr bool TALL_OK = ACT == 0 || ACT == 1 || ACT == 2;
+        if (TALL_OK && mode320 && !has_rest) {
+            const int tm10 = (p.M + 319) / 320;
+            const long c8 = (long)((tm * tn + 255) / 256) * 8, c10 = (long)((tm10 * tn + 255) / 256) * 10;
+            tall = mode320 == 2 || c10 < c8;
+            if (tall) tm = tm10;
+        }
         p.tiles_m = tm; p.tiles_n = tn;
         const int grid256 = p.tiles_m * p.tiles_n;
+        if constexpr (TALL_OK) {
+            if (tall) {
+                const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2);
+                if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
+                else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
+                return dclip_check_launch("dclip_gemm_nt");
+            }
+        }
         const size_t lds256 = 8 * HT;
-        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true>), dim3(grid256), dim3(512), lds256, st, p);
-        else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false>), dim3(grid256), dim3(512), lds256, st, p);
+        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 8>), dim3(grid256), dim3(512), lds256, st, p);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8>), dim3(grid256), dim3(512), lds256, st, p);
         if (!has_rest) return dclip_check_launch("dclip_gemm_nt");
         p = rest;
         p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;

@@ -210,3 +210,40 @@ def test_gemm_nt_row_split_between_tile_sizes(M, N, K):
     x = res.clone()
     ops.gemm_nt(a, b, bias=bias, residual=x, out=x)                       # in-place residual stream
     _close(x, ref + bias + res, 1e-4)
+
+
+@pytest.mark.parametrize('M,N,K', [(25600, 768, 128), (25610, 768, 64), (39424, 512, 192), (20480, 1024, 64), (25600, 768, 768)])
+def test_gemm_nt_320_row_tile_variant(M, N, K):
+    """Shapes whose 256^2 tiling leaves a nearly empty last round on 256 CUs ([25600, 768] = 300 tiles, [39424, 512] = 308) run on
+    320 x 256 tiles (240 / 248 workgroups, one round): full and ragged last row tile, every epilogue the towers use with it
+    (bias, f32 + residual, in-place residual, QuickGELU / GELU + saved pre-activation, positional row table, column sums), and
+    bit-identical repeats (LDS-DMA races show as run-to-run differences)."""
+    from distillclip_amd import ops
+    a, b = _rand((M, K), 41), _rand((N, K), 42, 0.2)
+    ref = a.float() @ b.float().t()
+    _close(ops.gemm_nt(a, b, out_dtype=torch.float32), ref, 1e-5 * K ** 0.5 + 1e-5)
+    o1 = ops.gemm_nt(a, b)
+    _close(o1, ref, 6e-3)
+    for _ in range(4):
+        assert torch.equal(ops.gemm_nt(a, b), o1)
+    bias = torch.randn(N, device='cuda')
+    res = torch.randn(M, N, device='cuda')
+    cs = torch.zeros(N, device='cuda')
+    out = ops.gemm_nt(a, b, bias=bias, residual=res, out_dtype=torch.float32, colsum=cs)
+    _close(out, ref + bias + res, 1e-4)
+    _close(cs, out.sum(0), 3e-4)
+    x = res.clone()
+    ops.gemm_nt(a, b, bias=bias, residual=x, out=x)                       # in-place residual stream (teacher towers)
+    _close(x, ref + bias + res, 1e-4)
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    z = ref + bias
+    q = ops.gemm_nt(a, b, bias=bias, act='quickgelu')
+    _close(q, z * torch.sigmoid(1.702 * z), 6e-3)
+    g = ops.gemm_nt(a, b, bias=bias, act='gelu', aux_out=aux)
+    _close(g, torch.nn.functional.gelu(z), 6e-3)
+    _close(aux, z, 6e-3)
+    G = 50
+    if M % G == 0:
+        pos = torch.randn(G, N, device='cuda')
+        o = ops.gemm_nt(a, b, out_dtype=torch.float32, row_group=G, rowadd=pos)
+        _close(o.view(M // G, G, N), ref.view(M // G, G, N) + pos, 1e-4)
