@@ -2,6 +2,7 @@
 //   reference: model/component/_common.py:14-20 (fp32 LayerNorm), nn.LayerNorm in weight_share_model.py:239,
 //   call sites _common.py:123,125,208,210 ; text_encoder.py:69 ; weight_share_model.py:181,183,363,503.
 // One wave per row, the row lives in registers (float4 chunks, D <= 1024), two-pass mean / variance.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -190,8 +191,15 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
     DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx_acc, "dclip_layernorm_bwd: null operand");
     DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
     const int nv = (int)((D + 255) / 256);
+    // persistent grid: every block ends with 3 x D float atomics (dgamma, dbeta, column sums), so the block count trades
+    // bytes in flight against atomic traffic.  Measured (tools/diag/ln_bench.py, sustained, 25600 / 39424 rows x 768): 1024 blocks
+    // 4.99 / 4.49 TB/s, 768 blocks 5.33 / 5.41, 512 blocks 5.67 / 5.03, 256 blocks 5.08 / 3.31 -> ~12 rows of 768 per wave.
     int blocks = (int)((M + 3) / 4);
-    if (blocks > 1024) blocks = 1024;
+    static const int force_blocks = [] { const char* e = getenv("DCLIP_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+    int want = (int)(((double)M * (double)D / (4.0 * 12.0 * 768.0) + 128.0) / 256.0) * 256;
+    want = want < 256 ? 256 : (want > 1024 ? 1024 : want);
+    if (force_blocks > 0) want = force_blocks;
+    if (blocks > want) blocks = want;
     // algorithmic bytes: read dy (2 or 4), x (4), dx_acc (4) ; write dx_acc (4) + optional bf16 copy (2)
     TraceScope tr(DCLIP_TRACE_LN_BWD, 12.0 * (double)M * D, (double)M * D * ((dy_f32 ? 4.0 : 2.0) + 12.0 + (dx_bf16 ? 2.0 : 0.0)), stream, (int)M, (int)D, 0, 0);
     hipStream_t st = (hipStream_t)stream;
