@@ -18,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6          # steps + warmup (+2 probe steps) executed under --stats
+title = sys.argv[3] if len(sys.argv) > 3 else 'l_clip dual step, B=512, 1x MI355X'
 
 
 def short(n):
@@ -78,7 +79,7 @@ if fs:
     json.dump(mfma, open(os.path.join(out, f'{tag}_mfma_util.json'), 'w'), indent=1, sort_keys=True)
 
 with open(os.path.join(out, f'{tag}_summary.md'), 'w') as f:
-    f.write(f'# rocprofv3 --kernel-trace --stats, bench.py (l_clip dual step, B=512, 1x MI355X) — {tag}\n\n')
+    f.write(f'# rocprofv3 --kernel-trace --stats, bench.py ({title}) — {tag}\n\n')
     f.write(f'total GPU kernel time {tot / 1e6:.1f} ms over the run ({steps} steps incl. warm-up / probe)\n\n')
     f.write('| kernel family | launches | total ms | avg us | % |\n|---|---|---|---|---|\n')
     for k, (c, v) in sorted(fam.items(), key=lambda x: -x[1][1])[:24]:
