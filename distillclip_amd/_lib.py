@@ -63,7 +63,7 @@ class _Lib:
 
     def __getattr__(self, name):
         fn = getattr(self._dll, name)
-        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name in ('dclip_version', 'dclip_encoder_num_grad_buckets') or name.endswith('_supported'):
+        if self.protos.get(name, (None,))[0] is not ctypes.c_int or name in ('dclip_version', 'dclip_encoder_num_grad_buckets') or name.endswith('_supported'):   # plain values, not status codes
             return fn
 
         def call(*args):

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
     const bool live = blockIdx.x * 4 + wave < nprob;
     const int b = prob / p.H, h = prob % p.H;
     const int n32 = (p.N + 31) & ~31;
-    char* tile = smem + wave * (NMAX * ROWB);
+    char* tile = smem + wave * (n32 * ROWB);        // sized by the padded sequence, not by NMAX: N = 50 fits 6 workgroups per CU instead of 3
     wave_stage<ROWB>(p.Bm + (int64_t)b * p.N * p.ldb + h * HD, p.ldb, 0, p.N, n32, HD, tile, lane);
     __syncthreads();
     const bf16_t* A = (const bf16_t*)p.A + ((int64_t)b * p.H + h) * p.N * p.lda;
@@ -1111,8 +1111,9 @@ extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 2);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 32) hipLaunchKernelGGL((attn_nn_kernel<32>), grid, dim3(256), 4 * NMAX * (32 * 2 + 32), st, p);
-    else hipLaunchKernelGGL((attn_nn_kernel<64>), grid, dim3(256), 4 * NMAX * (64 * 2 + 32), st, p);
+    const size_t n32 = ((size_t)N + 31) & ~(size_t)31;
+    if (hd == 32) hipLaunchKernelGGL((attn_nn_kernel<32>), grid, dim3(256), 4 * n32 * (32 * 2 + 32), st, p);
+    else hipLaunchKernelGGL((attn_nn_kernel<64>), grid, dim3(256), 4 * n32 * (64 * 2 + 32), st, p);
     return dclip_check_launch("dclip_attn_nn");
 }
 

@@ -120,6 +120,7 @@ struct ExecSave {          // per block execution (student training)
     float* x_mid; float* mean1; float* rstd1; float* mean2; float* rstd2;
     bf16_t *h1, *qkv, *P, *Rm, *ctx, *h2, *z, *u;
     float* S;
+    float* stats;          // [B, H, N] log-sum-exp rows of the register-resident attention path
 };
 
 struct Work {
@@ -139,6 +140,7 @@ struct Work {
     bf16_t *gb_f2, *gb_pr;                 // [R][M, D] bf16 residual gradient as seen by fc2 / attn.proj
     bf16_t *dbig, *dh, *dqkv, *dR, *dS, *dout;   // dbig [R][M, F], dqkv [R][M, 3D]
     float* tok_sum; float* demb;           // [N, D] ; compressed: [M, rank] f32
+    float* wg_dummy;                       // [2, H, H] sink for conv_l / conv_w gradients when those parameters are frozen
     size_t bytes;
 };
 
@@ -160,6 +162,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         shared.h1 = b.take<bf16_t>(M * D); shared.qkv = b.take<bf16_t>(M * 3 * D);
         shared.S = b.take<float>(SN); shared.P = (p.student && p.c.head_mix) ? b.take<bf16_t>(SN) : nullptr;
         shared.Rm = b.take<bf16_t>(SN);
+        shared.stats = b.take<float>(B * p.H * N);
         shared.ctx = b.take<bf16_t>(M * D); shared.h2 = shared.h1; shared.z = nullptr; shared.u = b.take<bf16_t>(M * F);
         shared.mean1 = shared.rstd1 = shared.mean2 = shared.rstd2 = nullptr;
     }
@@ -171,6 +174,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         s.mean1 = b.take<float>(M); s.rstd1 = b.take<float>(M); s.mean2 = b.take<float>(M); s.rstd2 = b.take<float>(M);
         s.qkv = b.take<bf16_t>(M * 3 * D);
         s.S = b.take<float>(SN); s.P = b.take<bf16_t>(SN); s.Rm = p.c.head_mix ? b.take<bf16_t>(SN) : s.P;
+        s.stats = b.take<float>(B * p.H * N);
         s.z = b.take<bf16_t>(M * F);
         if (e % p.R == 0) {
             // the wgrad operands (inputs of the four linears) of a block's R executions lie back to back: [R][M, .]
@@ -194,9 +198,10 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         w.dbig = b.take<bf16_t>(p.R * M * F); w.dh = b.take<bf16_t>(M * D); w.dqkv = b.take<bf16_t>(p.R * M * 3 * D);
         w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
         w.tok_sum = b.take<float>((int64_t)N * D);
+        w.wg_dummy = b.take<float>(2 * p.H * p.H);
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {
-        w.G = nullptr; w.Gb = nullptr; w.gb_f2 = w.gb_pr = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr;
+        w.G = nullptr; w.Gb = nullptr; w.gb_f2 = w.gb_pr = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr; w.wg_dummy = nullptr;
     }
     w.bytes = b.off;
 }
@@ -210,6 +215,16 @@ inline const float* PF(const void* const* params, int i) { return (const float*)
 inline bool fused_student_attn(const Plan& p, int64_t N) {
     static const int mode = [] { const char* e = getenv("DCLIP_FUSED_ATTN"); return e ? atoi(e) : 0; }();
     return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_student_fwd_supported(p.H, N, p.hd) != 0;
+}
+
+// DCLIP_ATTN_MIX=1 (opt-in): head-mixing students whose shape has a register-resident instantiation (attention_mix.hip) keep S,
+// A, P, dR out of HBM; forward and backward must agree (the backward recomputes from qkv + the forward's softmax statistics).
+// Off by default: correct (kernel-level and tower-level parity tests run it), but at 2 waves per SIMD the register mixes are
+// bound by the weight-operand fetch, not by the VALU: 247 / 1190 us (forward / backward score stage, text student, B = 512)
+// against 202 / 247 us for the unfused kernels (tools/diag/attn_mix_bench.py).
+inline bool mix_attn(const Plan& p, int64_t N) {
+    static const int mode = [] { const char* e = getenv("DCLIP_ATTN_MIX"); return e ? atoi(e) : 0; }();
+    return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_mix_supported(p.H, N, p.hd) != 0;
 }
 
 // split count of the wgrad contraction: minimise  rounds(tiles*s / 512 resident workgroups) * work per workgroup
@@ -375,7 +390,10 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
             // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
             CK(dclip_attn_fused_fwd(s.qkv, 3 * D, s.ctx, D, B, H, N, hd, scale, p.c.causal, st));
         } else {
-            if (wl && fused_student_attn(p, N)) {
+            if (wl && mix_attn(p, N)) {
+                CK(dclip_attn_mix_fwd(s.qkv, 3 * D, wl, ww, s.Rm, s.stats, B, H, N, Np, hd, scale, st));
+                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+            } else if (wl && fused_student_attn(p, N)) {
                 CK(dclip_attn_student_fwd(s.qkv, 3 * D, wl, ww, s.S, s.P, s.Rm, s.ctx, D, B, H, N, Np, hd, scale, st));
             } else {
                 CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
@@ -490,10 +508,16 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), st));
         bf16_t* dctx = w.dh;
         CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));                   // dR = dO V^T
         CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                         // dV = R^T dO
-        CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
-                                  wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
+        if (wl && mix_attn(p, N)) {
+            float* gl = GR(sr.cl) ? GR(sr.cl) : w.wg_dummy;
+            float* gw = GR(sr.cw) ? GR(sr.cw) : w.wg_dummy + H * H;
+            CK(dclip_attn_mix_bwd(s.qkv, 3 * D, dctx, D, wl, ww, s.stats, w.dS, gl, gw, B, H, N, Np, hd, scale, st));
+        } else {
+            CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));               // dR = dO V^T
+            CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
+                                      wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
+        }
         CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, st));                      // dQ = dS K
         CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                      // dK = dS^T Q
         if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), st));

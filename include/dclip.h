@@ -124,6 +124,25 @@ int dclip_attn_student_fwd_supported(int64_t H, int64_t N, int64_t hd);
 int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* S, void* P, void* R, void* ctx,
                            int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 
+/*
+ * Head-mixed student attention with the score tensors kept in registers (attention_mix.hip; reference
+ * weight_share_model.py:101-125).  One wave per (sample, 16 query rows): S = scale q k^T, A = conv_l(S), P = softmax(A),
+ * R = conv_w(P) are produced and consumed in the MFMA accumulator layout; only R (bf16 [B,H,N,Np], pad columns zero) and the
+ * softmax statistics (f32 [B,H,N]: log-sum-exp of every row of A) are stored.  The backward recomputes S, A, P from the
+ * packed qkv rows, forms dR = dO v^T on the fly and writes dS (bf16, gradient of the scaled pre-mix scores) plus
+ * dWl / dWw += [H,H] (f32 atomics).  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
+ *   forward   dclip_attn_mix_fwd -> dclip_attn_nn(R, v) ;   backward   dclip_attn_tn(R, dO) -> dV, dclip_attn_mix_bwd -> dS,
+ *             dclip_attn_nn(dS, k) -> dQ, dclip_attn_tn(dS, q) -> dK.
+ * Replaces dclip_attn_nt + dclip_attn_softmax_fwd and dclip_attn_nt + dclip_attn_softmax_bwd (S f32, P, dR never stored).
+ * dclip_attn_mix_supported: H in {2, 4, 8, 12}, hd in {32, 64}, N <= 128 (other shapes use the unfused kernels).
+ */
+int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd);
+int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* R, float* stats, int64_t B, int64_t H,
+                       int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
+int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo, const float* Wl, const float* Ww,
+                       const float* stats, void* dS, float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np,
+                       int64_t hd, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Embedding-side helpers (HBM-bound).
  * cast_bf16            : f32 -> bf16 copy (per-step weight down-cast).

@@ -207,6 +207,59 @@ def test_fused_student_attention_forward(B, N, H, hd):
     _close(dww_a, dww_b, 3e-2, 'dWw')
 
 
+@pytest.mark.parametrize('B,N,H,hd', [(3, 77, 12, 64), (2, 17, 4, 32), (3, 13, 2, 64), (2, 50, 12, 32), (1, 101, 8, 64), (5, 16, 4, 64),
+                                      (2, 128, 12, 64), (1, 1, 2, 64)])
+def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
+    """dclip_attn_mix_fwd / _bwd (attention_mix.hip; reference weight_share_model.py:101-125): S, A, P, dR live only in registers.
+    Forward R and the softmax statistics against an fp32 graph on the same bf16 q, k; backward dS, dW_l, dW_w against autograd of
+    that graph with dR = dO v^T; and the whole attention (ctx, dq, dk, dv through the unchanged nn / tn products) against the
+    unfused three-kernel path on the same inputs."""
+    from distillclip_amd import ops
+    D = H * hd
+    Np = (N + 7) // 8 * 8
+    qkv = _randn((B * N, 3 * D), 51, 0.7, torch.bfloat16)
+    wl = torch.eye(H, device='cuda') + _randn((H, H), 52, 0.15)
+    ww = torch.eye(H, device='cuda') + _randn((H, H), 53, 0.15)
+    scale = hd ** -0.5
+    R, lse = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)
+    q, k, v = (_heads(qkv[:, i * D:(i + 1) * D], B, N, H, hd) for i in range(3))
+    sr = ((q @ k.transpose(-1, -2)) * scale).requires_grad_(True)
+    wlr, wwr = wl.clone().requires_grad_(True), ww.clone().requires_grad_(True)
+    a = torch.einsum('gh,bhij->bgij', wlr, sr)
+    rr = torch.einsum('gh,bhij->bgij', wwr, a.softmax(-1))
+    _close(R[..., :N], rr, 5e-3, 'R')
+    _close(lse, torch.logsumexp(a, -1), 1e-5, 'log-sum-exp rows')
+    assert torch.count_nonzero(R[..., N:]) == 0
+    # backward of the score stage
+    d_ctx = _randn((B * N, D), 54, 1.0, torch.bfloat16)
+    do = _heads(d_ctx, B, N, H, hd)
+    rr.backward(do @ v.transpose(-1, -2))                               # dR = dO v^T
+    dwl, dww = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
+    dS = ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww)
+    _close(dS[..., :N], sr.grad, 1e-2, 'dS')
+    assert torch.count_nonzero(dS[..., N:]) == 0
+    _close(dww, wwr.grad, 2e-2, 'dWw')                                  # bf16 operands of the weight-gradient MFMAs
+    _close(dwl, wlr.grad, 2e-2, 'dWl')
+    # against the unfused kernels on the same inputs (what the towers ran before)
+    s3 = ops.attn_nt(qkv, 3 * D, qkv[:, D:], 3 * D, B, H, N, hd, alpha=scale)
+    p3, r3 = ops.attn_softmax_fwd(s3, wl, ww, save_p=True)
+    _close(R[..., :N], r3[..., :N], 8e-3, 'R vs three kernels')
+    dr3 = ops.attn_nt(d_ctx, D, qkv[:, 2 * D:], 3 * D, B, H, N, hd, alpha=1.0, out_dtype=torch.bfloat16)
+    dwl3, dww3 = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
+    ds3 = ops.attn_softmax_bwd(dr3, p3, s3, wl, ww, dwl3, dww3)
+    if N > 1:                                                           # N = 1: dS is exactly 0 here, bf16 rounding noise there
+        _close(dS[..., :N], ds3[..., :N], 1.5e-2, 'dS vs three kernels')
+    if N > 1:
+        _close(dwl, dwl3, 3e-2, 'dWl vs three kernels')
+        _close(dww, dww3, 3e-2, 'dWw vs three kernels')
+    # accumulation semantics of the weight gradients (+=) and run-to-run stability of the stored tensors
+    dS2 = ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww)
+    assert torch.equal(dS2, dS)
+    _close(dww, 2 * wwr.grad, 2e-2, 'dWw accumulates')
+    R2, lse2 = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)
+    assert torch.equal(R2, R) and torch.equal(lse2, lse)
+
+
 def test_fused_student_attention_support_matrix():
     from distillclip_amd._lib import lib
     assert lib().dclip_attn_student_fwd_supported(24, 50, 32) and lib().dclip_attn_student_fwd_supported(12, 77, 64)
