@@ -153,12 +153,14 @@ __global__ __launch_bounds__(512) void attn_mix_fwd_kernel(MixFwd p, const float
     const int nb = (p.N + 15) >> 4;
     const int tile_bytes = 16 * p.D * 2;
 
-    // The mix weights are read from LDS (all lanes the same address: one broadcast access, vectorised 16 bytes at a time).  As
-    // scalar operands they do not fit the SGPR file (2 H^2 values), and re-fetching them through the scalar cache inside every
-    // mix made the kernel scalar-load-latency bound (10x the VALU time).
-    float* Wl = (float*)(smem + 2 * tile_bytes);
-    float* Ww = Wl + H * H;
-    for (int idx = threadIdx.x; idx < H * H; idx += blockDim.x) { Wl[idx] = Wl_g[idx]; Ww[idx] = Ww_g[idx]; }
+    // The mix weights are scalar operands (wave-uniform s_loads).  The 2 H^2 values do not fit the SGPR file, so every mix
+    // re-fetches them through the scalar cache, and at 2 waves per SIMD that latency is what bounds this kernel (several times the
+    // VALU time).  Through LDS broadcast reads instead, the compiler hoists them into VGPRs and spills (352 us against 247 us,
+    // text student, B = 512); on the matrix pipe (4 x 4 lane-group transposes by v_permlane{16,32}_swap + 16x16x16 MFMA with the
+    // mix matrix as a constant A operand) the weight fetch disappears: 171 us in a first version, not finished this round
+    // (DESIGN.md section 7c).
+    const float* __restrict__ Wl = Wl_g;
+    const float* __restrict__ Ww = Ww_g;
     bf16x8 qf[H][KS];
 #pragma unroll
     for (int h = 0; h < H; ++h)
@@ -277,10 +279,8 @@ __global__ __launch_bounds__(256) void attn_mix_bwd_kernel(MixBwd p, const float
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* tx = smem + wave * 2 * WG_TILE;
     char* ty = tx + WG_TILE;
-    float* Wl = (float*)(smem + 4 * 2 * WG_TILE);        // mix weights from LDS (broadcast reads), see the forward kernel
-    float* Ww = Wl + H * H;
-    for (int idx = threadIdx.x; idx < H * H; idx += 256) { Wl[idx] = Wl_g[idx]; Ww[idx] = Ww_g[idx]; }
-    __syncthreads();
+    const float* __restrict__ Wl = Wl_g;                 // scalar operands (see the forward kernel)
+    const float* __restrict__ Ww = Ww_g;
     // rows >= H of the tiles are never written: zero them once so that the ignored part of the MFMA tile stays finite
     for (int idx = lane; idx < 2 * WG_TILE / 16; idx += 64) ((u32x4*)tx)[idx] = u32x4{0u, 0u, 0u, 0u};
     const int c = lane & 15, g4 = lane >> 4;
@@ -416,7 +416,7 @@ extern "C" int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, 
     MixFwd p{(const bf16_t*)qkv, ld, Wl, Ww, (bf16_t*)R, stats, (int)B, (int)N, (int)Np, (int)(H * hd), QT, scale};
     DCLIP_REQUIRE((H * hd) % 128 == 0, "dclip_attn_mix_fwd: width %ld must be a multiple of 128", (long)(H * hd));
     const dim3 grid((unsigned)B);                    // one workgroup per sample, one wave per 16-query tile
-    const size_t lds = (size_t)2 * 16 * H * hd * 2 + 2 * H * H * 4;  // double-buffered key block + the two mix matrices
+    const size_t lds = (size_t)2 * 16 * H * hd * 2;  // double-buffered key block
     const double el = (double)B * H * N * Np;
     TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd + 8.0 * el * H, 2.0 * el + 4.0 * B * N * H * hd, stream, (int)(B * H), (int)N, (int)hd, 7);
     MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_>), grid, dim3(QT * 64), lds, (hipStream_t)stream, p, Wl, Ww));
@@ -434,7 +434,7 @@ extern "C" int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, i
     MixBwd p{(const bf16_t*)qkv, ld, (const bf16_t*)dO, ldo, Wl, Ww, stats, (bf16_t*)dS, dWl, dWw, (int)B, (int)N, (int)Np, (int)(H * hd), QT, scale};
     int blocks = (int)((B * QT + 3) / 4);
     if (blocks > 512) blocks = 512;              // persistent: the weight-gradient tiles end in 2 x H x H atomics per wave
-    const size_t lds = (size_t)4 * 2 * WG_TILE + 2 * H * H * 4;
+    const size_t lds = (size_t)4 * 2 * WG_TILE;
     const double el = (double)B * H * N * Np;
     TraceScope tr(DCLIP_TRACE_ATTN, 8.0 * B * H * N * N * hd + 20.0 * el * H, 2.0 * el + 8.0 * B * N * H * hd, stream, (int)(B * H), (int)N, (int)hd, 8);
     MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_bwd_kernel<HH, HD_>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, p, Wl, Ww));
