@@ -45,7 +45,8 @@ class _FusedLossFn(torch.autograd.Function):
                                       stats_only=True)
                 if world > 1:
                     allst = torch.empty((world, 6, B), dtype=torch.float32, device=st.device)
-                    dist.all_gather_into_tensor(allst.view(-1), st.view(-1))
+                    from ..parallel import all_gather_flat
+                    all_gather_flat(allst.view(-1), st.contiguous().view(-1))
                     gstats = allst.permute(1, 0, 2).reshape(6, world * B).contiguous()
                 else:
                     gstats = st

@@ -77,10 +77,15 @@ class FusedAdamW:
     def _step_sharded(self, tw):
         """reduce-scattered gradient shards -> AdamW on the owned slices -> all-gather of the updated parameters, all on the
         exchange stream behind the tower's reduce-scatters (which were released from inside its backward)."""
-        import torch.distributed as dist
+        from .parallel import all_gather_flat
         sync = tw.sync
         m, v = self._moments(tw)
         s = sync.stream_for(tw.flat)
+        if s is not None:
+            # whatever the caller's stream holds before step() must be visible on the exchange stream — in particular the
+            # zero-fill of freshly allocated m / v (first step): without this edge AdamW read uninitialised moments at world
+            # size 2 (NaN weights after one step; found by tests/test_parallel_gpu.py)
+            s.wait_stream(torch.cuda.current_stream())
         works = []
         with sync._On(s):
             st = s.cuda_stream if s is not None else None
@@ -91,9 +96,10 @@ class FusedAdamW:
                 for a, e in own_tr:
                     lo, hi = off + a - o0, off + e - o0
                     self._adamw(tw.flat[a:e], tw.gshard[lo:hi], m[lo:hi], v[lo:hi], False, st)
-                works.append(dist.all_gather_into_tensor(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True))
+                works.append(all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True))
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
         tw.wcache_dirty = True
         tw.grads_ready = None
         if s is not None:

@@ -24,6 +24,43 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+def _native():
+    """RCCL ("nccl") has reduce-scatter / all-gather / AVG on device tensors; gloo (CPU rehearsal, or the one-GPU multi-process test
+    of tests/test_parallel_gpu.py) gets the same results from all_reduce, which it supports for every tensor type"""
+    return dist.get_backend() == 'nccl'
+
+
+def reduce_scatter_avg(out, inp):
+    """out <- this rank's 1/W slice of the element-wise average of `inp` over the ranks"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if _native():
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG)
+        return
+    n = out.numel()
+    if not inp.is_cuda:
+        try:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+            out.mul_(1.0 / world)
+            return
+        except RuntimeError:
+            pass
+    tmp = inp.clone()
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+    out.copy_(tmp[rank * n:(rank + 1) * n]).mul_(1.0 / world)
+
+
+def all_gather_flat(out, inp, async_op=False):
+    """out[r * n:(r + 1) * n] <- rank r's `inp` (out may contain inp in place)"""
+    if _native() or not inp.is_cuda:
+        return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+    rank, n = dist.get_rank(), inp.numel()
+    tmp = torch.zeros_like(out)
+    tmp[rank * n:(rank + 1) * n].copy_(inp)
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+    out.copy_(tmp)
+    return None
+
+
 class _Shards:
     """Per-tower plan: which flat ranges travel together and which slice of each this rank owns."""
 
@@ -128,12 +165,7 @@ class GradSync:
                 after.record(torch.cuda.current_stream())
             s.wait_event(after)
         with GradSync._On(s):
-            out = tw.gshard[off:off + (o1 - o0)]
-            if g.is_cuda:
-                dist.reduce_scatter_tensor(out, g[b0:b1], op=dist.ReduceOp.AVG)
-            else:                                       # gloo has no AVG
-                dist.reduce_scatter_tensor(out, g[b0:b1], op=dist.ReduceOp.SUM)
-                out.mul_(1.0 / self.world)
+            reduce_scatter_avg(tw.gshard[off:off + (o1 - o0)], g[b0:b1])
             g[b0:b1].zero_()                            # the backward accumulates (+=): leave the bucket clean for the next step
 
     def finish(self, tw):
@@ -153,14 +185,14 @@ class GradSync:
         if b is None:
             return
         b0, b1, o0, o1, _, _ = b
-        dist.all_gather_into_tensor(tw.flat[b0:b1], tw.flat[o0:o1])
+        all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1])
 
     def gather_full(self, tw, shard):
         """[shard_elems] per-rank optimizer state -> full flat-layout tensor (checkpointing; collective)"""
         full = torch.zeros_like(tw.flat)
         for b in tw.dp.live():
             b0, b1, o0, o1, off, _ = b
-            dist.all_gather_into_tensor(full[b0:b1], shard[off:off + (o1 - o0)].contiguous())
+            all_gather_flat(full[b0:b1], shard[off:off + (o1 - o0)].contiguous())
         return full
 
     # ---- flat all-reduce (fallback; the reference's DDP semantics literally) -----------------------------------------------
@@ -227,7 +259,7 @@ def gather_embeddings(tensors):
     world, rank = dist.get_world_size(), dist.get_rank()
     packed = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()          # [B, k*E]: one fused gather
     out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out.view(-1, packed.shape[1]), packed)
+    all_gather_flat(out.view(-1), packed.view(-1))
     full = out.view(world * packed.shape[0], packed.shape[1])
     widths = [t.shape[1] for t in tensors]
     return [c.contiguous() for c in torch.split(full, widths, dim=1)], rank, world
