@@ -357,6 +357,10 @@ int dclip_trace_begin(int64_t max_records);
 int64_t dclip_trace_end(int32_t* kind, float* ms, double* flops, double* bytes, int64_t cap);
 /* problem sizes of the traced calls so far, 4 ints per record (GEMM: M, N, K, variant bits); call before dclip_trace_end */
 int64_t dclip_trace_dims(int32_t* dims, int64_t cap);
+/* profiling only (process-global): while `buf` is non-NULL every workgroup of the 256- / 320-row dclip_gemm_nt kernels writes 6
+ * uint64 stamps to buf[6 * workgroup ..]: s_memtime at start / first operands landed / main loop done / epilogue done, then
+ * s_memrealtime (100 MHz) at start / end (tools/diag/gemm_phases.py).  NULL switches it off. */
+int dclip_trace_gemm_stamps(void* buf);
 
 #ifdef __cplusplus
 }

@@ -348,5 +348,7 @@ def test_reduce_scatter_sharded_path_over_rccl_world1_equals_plain_path():
     for k in plain:
         # wgrad atomics are not bit-reproducible between runs and Adam's m / sqrt(v) turns a rounding-level gradient
         # difference into up to +-lr per step on near-zero-gradient elements: 3 steps at lr 1e-3
+        # (the k-third of attn.qkv.bias has an exactly-zero true gradient — softmax is shift-invariant — so there every element is
+        #  such a near-zero-gradient element and only the +-lr-per-step bound holds)
         d = (plain[k] - sharded[k]).abs()
-        assert d.max() < 3e-3 and d.mean() < 2e-5, (k, d.max().item(), d.mean().item())
+        assert d.max() < 3e-3 and d.mean() < (1e-3 if 'qkv.bias' in k else 2e-5), (k, d.max().item(), d.mean().item())
