@@ -1049,9 +1049,8 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
         // loads carry no duplicates); DCLIP_GEMM320=0 disables the 320-row variant, =2 forces it
         static const int mode320 = [] { const char* e = getenv("DCLIP_GEMM320"); return e ? atoi(e) : 1; }();
         bool tall = false;
-        // (the DGELU / MULAUX epilogues keep side operands in registers ahead of the LDS staging: with 160 accumulator registers
-        //  that spills, so those variants stay on the 256-row tile)
-        constexpr bool TALL_OK = ACT == 0 || ACT == 1 || ACT == 2;
+        // (every epilogue variant fits the 160 accumulator registers of the 320-row tile without spilling: tools/diag/regs.py)
+        constexpr bool TALL_OK = true;
         if (TALL_OK && mode320 && !has_rest) {
             const int tm10 = (p.M + 319) / 320;
             const long c8 = (long)((tm * tn + 255) / 256) * 8, c10 = (long)((tm10 * tn + 255) / 256) * 10;
