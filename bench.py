@@ -386,6 +386,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_issue = time.perf_counter() - t0                      # host time to enqueue the steps (the GPU runs behind it)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -393,7 +394,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
-    log(f'{args.steps} steps in {dt:.3f} s; loss {final_loss:.5f}')
+    log(f'{args.steps} steps in {dt:.3f} s (host enqueue {t_issue:.3f} s); loss {final_loss:.5f}')
 
     roofline = None
     if not args.no_roofline:
@@ -473,6 +474,7 @@ def main():
             f'step_gflop_per_{wl["unit"][:-1]}': wl['gflop'],
             'mfma_roofline_frac_whole_step': round(value / world * wl['gflop'] * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             'final_loss': round(final_loss, 6),
+            'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
         }
         if roofline is not None:
             out['roofline'] = roofline

@@ -36,6 +36,7 @@ struct GemmNT {
     int tiles_m, tiles_n;
     int preload;                                    // epilogue: fetch residual / aux rows of a slab ahead of its LDS staging
     unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps): 6 x u64 per workgroup, else null
+    int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
 };
 
 __device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }
@@ -300,18 +301,18 @@ struct EpiSide {
 // (the residual travels in EpiSide only with f32 output — the in-place residual stream; with bf16 output it cannot alias C and
 //  is read inline)
 template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int row, int col, EpiSide& sd) {
-    const int64_t o = (int64_t)row * p.ldc + col;
+__device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int64_t o, int64_t orr, EpiSide& sd) {
     if (OUT_F32 && p.residual) {
-        const float* rp = p.residual + (int64_t)row * p.ldr + col;
+        const float* rp = p.residual + orr;
         sd.r0 = *(const float4*)rp; sd.r1 = *(const float4*)(rp + 4);
     }
     if (ACT == 3 || ACT == 4) sd.z = *(const bf16x8*)(p.aux_in + o);
 }
 
 template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, const float (&bias)[8],
-                                              float (&csum)[8], const EpiSide& sd) {
+__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, int64_t o, int64_t orr,
+                                              const float (&bias)[8], float (&csum)[8], const EpiSide& sd) {
+    // o = row * ldc + col, orr = row * ldr + col (formed incrementally by the caller)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
     if (p.row_group > 0) {      // (patch-embedding GEMM only: the position-embedding rows, L2-resident)
@@ -319,7 +320,6 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
         const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
     }
-    const int64_t o = (int64_t)row * p.ldc + col;
     if (ACT != 5 && p.aux_out) {
         bf16x8 z;
 #pragma unroll
@@ -358,7 +358,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
         float4 r0, r1;
         if (OUT_F32) { r0 = sd.r0; r1 = sd.r1; }
         else {
-            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            const float* rp = p.residual + orr;
             r0 = *(const float4*)rp; r1 = *(const float4*)(rp + 4);
         }
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
         for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
         *(bf16x8*)((bf16_t*)p.C + o) = ov;
     }
-    if (!OUT_F32) {
+    if (!OUT_F32 && p.colsum) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
     }
@@ -397,9 +397,21 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
+    // Tile raster inside an XCD's chunk: groups of group_n column tiles, rows fastest-but-one.  With n fastest over ALL column
+    // tiles the 32 concurrent tiles of an XCD span every B panel (N = 3072, K = 768: 4.7 MB, more than the 4 MB L2), so B is
+    // re-streamed from beyond L2 once per round; with a group whose B panels stay L2-resident an XCD streams its A rows once
+    // per group and reads B once (host-side choice and traffic model: launch_nt).
     const int nwg = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    int tm, tn;
+    if (p.group_n >= p.tiles_n) { tm = t / p.tiles_n; tn = t % p.tiles_n; }
+    else {
+        const int per = p.tiles_m * p.group_n;
+        const int gi = t / per, rem = t - gi * per;
+        const int left = p.tiles_n - gi * p.group_n;
+        const int gw = left < p.group_n ? left : p.group_n;
+        tm = rem / gw; tn = gi * p.group_n + rem % gw;
+    }
     const int m0 = tm * BMT, n0 = tn * 256;
     const int nk = p.K / BK;
     const int nload = 4 * nk;
@@ -547,9 +559,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     constexpr int NB = !SIDE ? 1 : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : 6)) : 8);
     constexpr int NU = 2 * MI;
     EpiSide side[NB];
+    const int row0 = m0 + wr * AROWS + rl;
+    const int64_t o0 = (int64_t)row0 * p.ldc + colb, r0off = (int64_t)row0 * p.ldr + colb;
+    const int64_t ostep = 16 * p.ldc, rstep = 16 * p.ldr;
     auto load_side = [&](int u, EpiSide& sd) {
-        const int row = m0 + wr * AROWS + (u >> 1) * 16 + rl, col = colb + (u & 1) * 32;
-        if (row < p.M && col < p.N) epilogue_load_side<ACT, OUT_F32>(p, row, col, sd);
+        const int i = u >> 1, jp = u & 1;
+        if (row0 + i * 16 < p.M && colb + jp * 32 < p.N) epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, sd);
     };
     if (SIDE) {
 #pragma unroll
@@ -559,12 +574,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     for (int u = 0; u < NU; ++u) {
         const int i = u >> 1, jp = u & 1;
         if (SIDE && u + NB - 1 < NU) load_side(u + NB - 1, side[(u + NB - 1) % NB]);
-        const int row = m0 + wr * AROWS + i * 16 + rl, col = colb + jp * 32;
+        const int row = row0 + i * 16, col = colb + jp * 32;
         if (row < p.M && col < p.N) {
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-            epilogue_vec8<ACT, OUT_F32>(p, v, row, col, bias[jp], csum[jp], side[SIDE ? u % NB : 0]);
+            epilogue_vec8<ACT, OUT_F32>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                                        side[SIDE ? u % NB : 0]);
         }
     }
     if (!OUT_F32 && p.colsum) {     // (f32 output + column sums: launch_nt routes that combination to the 128^2 kernel)
@@ -1059,6 +1075,21 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
         }
         p.tiles_m = tm; p.tiles_n = tn;
         const int grid256 = p.tiles_m * p.tiles_n;
+        // raster group width: minimise the modelled operand bytes from beyond L2 —  A once per group, B once per XCD while a
+        // group's B panels (256 x K bf16 each) fit ~2.5 MB of the XCD's 4 MB L2, else once per round of 32 tiles per XCD
+        {
+            static const int force_g = [] { const char* e = getenv("DCLIP_GEMM_GROUPN"); return e ? atoi(e) : 0; }();
+            const double panel = 512.0 * (double)p.K, a_bytes = 2.0 * (double)p.M * (double)p.K;
+            double best = 0.0; int best_g = tn;
+            for (int g = 1; g <= tn; ++g) {
+                const int ngroups = (tn + g - 1) / g;
+                const double b_term = (g * panel <= 2.5e6) ? 8.0 * g * panel * (ngroups > 8 ? ngroups / 8.0 : 1.0)
+                                                           : (double)grid256 / 32.0 * g * panel;
+                const double cost = a_bytes * ngroups + b_term;
+                if (g == 1 || cost < best * 0.999) { best = cost; best_g = g; }
+            }
+            p.group_n = force_g > 0 ? force_g : best_g;
+        }
         if constexpr (TALL_OK) {
             if (tall) {
                 const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2);
@@ -1111,6 +1142,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     static const int epi_preload = [] { const char* e = getenv("DCLIP_EPI_PRELOAD"); return e ? atoi(e) : 1; }();
     p.preload = epi_preload;
     p.stamps = g_gemm_stamps;
+    p.group_n = 1 << 30;
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
                   2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream, (int)M, (int)N, (int)K,

@@ -247,3 +247,44 @@ def test_gemm_nt_320_row_tile_variant(M, N, K):
         pos = torch.randn(G, N, device='cuda')
         o = ops.gemm_nt(a, b, out_dtype=torch.float32, row_group=G, rowadd=pos)
         _close(o.view(M // G, G, N), ref.view(M // G, G, N) + pos, 1e-4)
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 3072, 768), (25600, 2312, 128), (2100, 520, 192), (39424, 3072, 64)])
+def test_gemm_nt_register_epilogue_variants(M, N, K):
+    """The 256- / 320-row kernels store straight from the accumulators (operand-swapped MFMA, permuted B staging): every epilogue
+    variant with bf16 output, including the column sums reduced by lane shuffles (the dgrad GEMMs' bias gradients), on shapes that
+    exercise the grouped tile raster (12 column tiles, K = 768), a ragged last column tile (N = 2312, 520), ragged rows, and the
+    320-row tile with the DGELU / MULAUX / GELU-saving epilogues."""
+    from distillclip_amd import ops
+    a, b = _rand((M, K), 51), _rand((N, K), 52, 0.2)
+    ref = a.float() @ b.float().t()
+    bias = torch.randn(N, device='cuda')
+    z = _rand((M, N), 53)
+    tol = 8e-3
+    # plain + bias, bf16, with column sums
+    cs = torch.zeros(N, device='cuda')
+    o = ops.gemm_nt(a, b, bias=bias, colsum=cs)
+    _close(o, ref + bias, tol)
+    _close(cs, o.float().sum(0), 2e-3)          # sums of the f32 values before the bf16 rounding of the stored copy
+    # MULAUX (dz = (dY W) o saved gelu') and DGELU, with column sums
+    for act, want in (('mulaux', ref * z.float()),
+                      ('dgelu', ref * torch.autograd.functional.vjp(torch.nn.functional.gelu, z.float(), torch.ones_like(ref))[1])):
+        cs = torch.zeros(N, device='cuda')
+        o = ops.gemm_nt(a, b, act=act, aux_in=z, colsum=cs)
+        _close(o, want, tol)
+        _close(cs, want.sum(0), 3e-3)
+    # GELU with the saved derivative (training towers' fc1)
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    zz = (ref + bias).requires_grad_(True)
+    g = torch.nn.functional.gelu(zz)
+    g.sum().backward()
+    o = ops.gemm_nt(a, b, bias=bias, act='gelu_save', aux_out=aux)
+    _close(o, g.detach(), tol)
+    _close(aux, zz.grad, tol)
+    # f32 output with a residual read through the side-operand ring, bf16 output with an (inline) residual
+    res = torch.randn(M, N, device='cuda')
+    _close(ops.gemm_nt(a, b, bias=bias, residual=res, out_dtype=torch.float32), ref + bias + res, 1e-4 * max(1.0, K ** 0.5 / 8))
+    _close(ops.gemm_nt(a, b, bias=bias, residual=res), ref + bias + res, tol)
+    o1 = ops.gemm_nt(a, b, bias=bias, act='quickgelu')
+    for _ in range(3):
+        assert torch.equal(ops.gemm_nt(a, b, bias=bias, act='quickgelu'), o1)
