@@ -290,6 +290,36 @@ __device__ __forceinline__ void stage_half160(const bf16_t* __restrict__ G, int6
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (rb * 2 + kb) * SUB), 16, 0, 0);
 }
 
+// A "row-half" of the two-phase schedule: the upper (dn = 0) or lower (dn = 1) RH row tiles of BOTH wave groups, written to
+// the same LDS addresses the fragment reads expect (group g's region at g * HTA, row tile i at sub-tiles 2 i, 2 i + 1).  Row
+// blocks 0-7 by wave; with RH = 5 the remaining two row blocks are split in four [16 x 32] pieces over waves 0-3 (waves 4-7
+// repeat them: every wave issues the same number of LDS-DMA instructions, so the counted vmcnt waits stay wave-independent).
+template <int RH>
+__device__ __forceinline__ void stage_rowhalf(const bf16_t* __restrict__ G, int64_t ld, int m0, int rows_max, int k0,
+                                              char* abase, int hta, int dn, int wave, int lane) {
+    const int L = lane * 16;
+    const int X = swz(L);
+    const int r = X >> 6, c = (X >> 4) & 3;
+    constexpr int AROWS = RH * 32;
+    {
+        const int g = wave / RH, i = wave % RH + dn * RH;          // row block `wave` of 2 RH
+        int row = m0 + g * AROWS + i * 16 + r;
+        row = row < rows_max ? row : rows_max - 1;
+        const bf16_t* src = G + (int64_t)row * ld + k0 + c * 8;
+        char* dst = abase + g * hta + (i * 2) * SUB;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(dst + SUB), 16, 0, 0);
+    }
+    if (RH == 5) {
+        const int e = wave & 3, rbk = 8 + (e >> 1), kb = e & 1;
+        const int g = rbk / RH, i = rbk % RH + dn * RH;
+        int row = m0 + g * AROWS + i * 16 + r;
+        row = row < rows_max ? row : rows_max - 1;
+        const bf16_t* src = G + (int64_t)row * ld + k0 + kb * 32 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(abase + g * hta + (i * 2 + kb) * SUB), 16, 0, 0);
+    }
+}
+
 // side operands of one output row segment, loaded ahead of use: residual and C may alias (in-place residual stream), so the
 // compiler cannot hoist these loads above the previous row's store by itself — left inside the row loop every row pays a
 // full HBM round trip in sequence
@@ -379,6 +409,9 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
     }
 }
 
+#ifndef DCLIP_GEMM_PHASES
+#define DCLIP_GEMM_PHASES 2
+#endif
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -422,6 +455,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if DCLIP_GEMM_PHASES == 2
+    // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_up (upper row tiles of both wave groups), 3 A_dn (lower row tiles)
+    auto issue = [&](int l) {
+        const int tile = l >> 2, w = l & 3;
+        char* par = smem + (tile & 1) * PAR;
+        if (w < 2) stage_half_perm(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, lane);
+        else stage_rowhalf<RH>(p.A, p.lda, m0, p.M, tile * BK, par + 2 * HT, HTA, w - 2, wave, lane);
+    };
+#else
     // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_lo, 3 A_hi
     auto issue = [&](int l) {
         const int tile = l >> 2, w = l & 3;
@@ -430,6 +472,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         else if (MI == 8) stage_half(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
         else stage_half160(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
     };
+#endif
     // profiling stamps (off unless dclip_trace_gemm_stamps armed them): s_memtime at start / first operands landed / main loop
     // done / epilogue done (stores acknowledged), s_memrealtime at start / end
     auto stamp = [&](int k) {
@@ -441,9 +484,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         }
     };
     stamp(0);
+#if DCLIP_GEMM_PHASES == 2
+    // LDS-DMA instructions per wave: B half 2, A row-half 2 (RH = 4) or 3 (RH = 5).  vmcnt completes in issue order, so "wait
+    // until half-tile X has landed" = vmcnt(number of instructions issued after X)
+#define WAIT_VM2(n8, n10) do { if (MI == 8) WAIT_VMCNT(n8); else WAIT_VMCNT(n10); } while (0)
+    const int npro = nload < 7 ? nload : 7;                // tile 0 entirely, tile 1: B_lo, B_hi, A_up
+    for (int l = 0; l < npro; ++l) issue(l);
+    if (nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);    // B_lo, B_hi, A_up of tile 0 landed (younger: A_dn(0), B, B, A_up(1))
+#else
     const int npro = nload < 5 ? nload : 5;
     for (int l = 0; l < npro; ++l) issue(l);
     if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);      // the youngest half-tile in flight is always a B half: 2 instructions
+#endif
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
@@ -453,6 +505,77 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
     bf16x8 af[RH][2], b0[2][2], b1[2][2];
 
+#if DCLIP_GEMM_PHASES == 2
+    // Two phases per K-tile: A = upper row tiles of the wave x all four column tiles, B = lower row tiles.  MFMA clusters of
+    // 4 RH instructions between barriers, 4 barriers per K-tile (the four-phase schedule kept under DCLIP_GEMM_PHASES=4 has 8).
+    // Load stream: the operands of phase A of tile kt + 1 (B_lo, B_hi, A_up) are requested in phase B of tile kt - 1, A_dn(kt + 1)
+    // in phase A of tile kt: every half-tile has two full phases (~2.5 k cycles) to land, which is what the loop needs when all
+    // 256 CUs pull operands at once (with one phase of slack the same loop stalled on vmcnt: 3 200 instead of 2 480 cycles per
+    // K-tile at 256 workgroups, while 32 workgroups ran at 2 500).  A wave waits for its own LDS reads BEFORE the phase's first
+    // barrier, so whoever has passed a barrier knows that every read issued before it has completed: the regions refilled by
+    // the next phase's loads are no longer being read.
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * PAR;
+        const char* ap = base + a_off + fragoff;
+        const char* bp = base + b_off + fragoff;
+        // ---------------- phase A : upper row tiles ----------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                b0[j][kb] = *(const bf16x8*)(bp + (j * 2 + kb) * SUB);
+                b1[j][kb] = *(const bf16x8*)(bp + ((2 + j) * 2 + kb) * SUB);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < RH; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + (i * 2 + kb) * SUB);
+        if (kt + 1 < nk) { issue(4 * (kt + 1) + 3); WAIT_VM2(8, 10); }  // request A_dn(kt + 1); A_dn(kt) landed (younger: B, B, A_up, A_dn(kt + 1))
+        else WAIT_VMCNT(0);
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < RH; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[i][2 + j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase B : lower row tiles ----------------
+#pragma unroll
+        for (int i = 0; i < RH; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + ((RH + i) * 2 + kb) * SUB);
+        // request B_lo, B_hi, A_up(kt + 2); B_lo, B_hi, A_up(kt + 1) landed (younger: A_dn(kt + 1) and the three just issued)
+        if (kt + 2 < nk) { issue(4 * (kt + 2)); issue(4 * (kt + 2) + 1); issue(4 * (kt + 2) + 2); WAIT_VM2(8, 10); }
+        else if (kt + 1 < nk) WAIT_VM2(2, 3);
+        else WAIT_VMCNT(0);
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < RH; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[RH + i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[RH + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[RH + i][2 + j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
         const char* base = smem + (kt & 1) * PAR;
         const char* ap = base + a_off + fragoff;
@@ -532,6 +655,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
     stamp(2);
 
@@ -1069,8 +1193,14 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
         constexpr bool TALL_OK = true;
         if (TALL_OK && mode320 && !has_rest) {
             const int tm10 = (p.M + 319) / 320;
-            const long c8 = (long)((tm * tn + 255) / 256) * 8, c10 = (long)((tm10 * tn + 255) / 256) * 10;
-            tall = mode320 == 2 || c10 < c8;
+            // rounds on 256 CUs x cycles per tile, from the in-kernel stamps (tools/diag/gemm_phases.py): prologue 3.3 k, main
+            // loop 2 750 (256 rows) / 3 200 (320 rows) cycles per k-tile — the taller tile does 1.25 x the work in 1.16 x the
+            // time — and an epilogue that scales with the rows (bf16 ~9.5 k, f32 + residual ~40 k when the whole chip stores)
+            static const double tall_bias = [] { const char* e = getenv("DCLIP_GEMM320_BIAS"); return e ? atof(e) : 1.0; }();
+            const double nkt = (double)(p.K / BK), e8 = out_f32 ? 40000.0 : (ACT == 0 || ACT == 4 ? 9500.0 : 14000.0);
+            const double c8 = (double)((tm * tn + 255) / 256) * (3300.0 + nkt * 2750.0 + e8);
+            const double c10 = (double)((tm10 * tn + 255) / 256) * (3300.0 + nkt * 3200.0 + 1.25 * e8);
+            tall = mode320 == 2 || c10 * tall_bias < c8;
             if (tall) tm = tm10;
         }
         p.tiles_m = tm; p.tiles_n = tn;
