@@ -1002,9 +1002,13 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         if (w < 2) stage_half_tn(p.B, p.ldb, m_begin + kt * TC, q0 + w * 128, buf, wave, lane);
         else stage_half_tn(p.A, p.lda, m_begin + kt * TC, p0 + (w - 2) * 128, buf, wave, lane);
     };
-    const int npro = nload < 5 ? nload : 5;
+    // Two phases per contraction chunk (rows 0-63 / 64-127 of the wave's 128 output rows x its 64 columns), as in
+    // gemm_nt256_kernel: 4 barriers per chunk, MFMA clusters of 32.  Loads run 6 half-tiles ahead (the A halves of chunk kt + 1
+    // are requested in phase A of chunk kt, the B halves of chunk kt + 2 in phase B); a wave retires its own LDS reads before
+    // the phase's first barrier, so a region is only refilled once nobody reads it any more.
+    const int npro = nload < 6 ? nload : 6;
     for (int l = 0; l < npro; ++l) issue(l);
-    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);
+    if (nload > 4) WAIT_VMCNT(4); else WAIT_VMCNT(0);      // (two B halves of chunk 1 stay in flight: 2 instructions each)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
@@ -1018,77 +1022,58 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         const char* at = base + a_off;
         const char* bt = base + b_off;
         const int k4 = kt * 4;
-        // phase 0 : rows 0-63 x cols 0-31
+        // phase A : rows 0-63
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) b0[j][kb] = tr_frag_swz(bt, kb * 32, bcol + j * 16, lane);
+            for (int kb = 0; kb < 2; ++kb) {
+                b0[j][kb] = tr_frag_swz(bt, kb * 32, bcol + j * 16, lane);
+                b1[j][kb] = tr_frag_swz(bt, kb * 32, bcol + (2 + j) * 16, lane);
+            }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, i * 16, lane);
-        if (k4 + 5 < nload) issue(k4 + 5);
-        __builtin_amdgcn_s_barrier();
+        if (k4 + 6 < nload) issue(k4 + 6);
+        if (k4 + 7 < nload) issue(k4 + 7);
         WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // phase 1 : rows 0-63 x cols 32-63
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) b1[j][kb] = tr_frag_swz(bt, kb * 32, bcol + (2 + j) * 16, lane);
-        if (k4 + 6 < nload) issue(k4 + 6);
-        __builtin_amdgcn_s_barrier();
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[i][2 + j], 0, 0, 0);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
-        // phase 2 : rows 64-127 x cols 32-63
+        // phase B : rows 64-127
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, (4 + i) * 16, lane);
-        if (k4 + 7 < nload) issue(k4 + 7);
-        __builtin_amdgcn_s_barrier();
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[4 + i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // phase 3 : rows 64-127 x cols 0-31
-        if (k4 + 8 < nload) { issue(k4 + 8); WAIT_VMCNT(2); }
+        if (k4 + 8 < nload) { issue(k4 + 8); issue(k4 + 9); WAIT_VMCNT(4); }       // chunk kt + 1 landed
         else WAIT_VMCNT(0);
+        WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b0[j][kb], acc[4 + i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kb], b1[j][kb], acc[4 + i][2 + j], 0, 0, 0);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
