@@ -226,34 +226,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// gemm_nt256: 256x256x64 tile, 8 waves (2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles, 128 accumulator registers),
-// one workgroup per CU (128 KiB LDS).  Structure after the guide's "256^2 8-phase" template, with our own schedule:
-//   * LDS = [2 parities][A_lo, A_hi, B_lo, B_hi] half-tiles of 128 rows x 64 k (16 KiB each, same swizzled sub-tile image
-//     as above); every half-tile is staged by all 8 waves (2 global_load_lds per wave).
-//   * a K-tile is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile).  Fragment reads per phase:
-//       phase 0: A rows 0-63 (8 frags) + B cols 0-31 (4)   phase 1: B cols 32-63 (4)   phase 2: A rows 64-127 (8)   phase 3: -
-//     quadrant order (0,0) (0,1) (1,1) (1,0), both B fragment sets stay in registers.
-//   * the load stream runs 5 phases ahead: phase k issues half-tile l = k + 5, l = 4*tile + {B_lo, B_hi, A_lo, A_hi}.
-//     WAR: the buffer's previous tile was last read >= 2 barriers earlier (B: phase 1, A: phase 2 of tile - 2).
-//     RAW: a counted s_waitcnt vmcnt(2) in phase 3 (all but the just-issued half-tile landed) + the two barriers that
-//     separate it from phase 0 of the next tile.  vmcnt never drains to 0 inside the loop.
+// gemm_nt256: 256x256x64 tile (MI = 8) or 320x256x64 (MI = 10), 8 waves (2 x 4, wave tile 16 MI x 64 = MI x 4 MFMA tiles,
+// 16 MI accumulator registers), one workgroup per CU (128 / 144 KiB LDS).  Structure after the guide's "256^2 8-phase"
+// template, with our own schedule (round 2: two phases per K-tile, measured with in-kernel stamps, tools/diag/gemm_phases.py):
+//   * LDS = [2 parities][B_lo, B_hi, A region of wave group 0, A region of wave group 1]; B halves are 128 rows x 64 k (16 KiB,
+//     the swizzled [16 x 32] sub-tile image of the 128^2 kernel), an A region holds the group's MI row tiles.  The load stream
+//     moves "half-tiles" staged by all 8 waves (2-3 global_load_lds per wave): B_lo, B_hi, A_up (the upper MI/2 row tiles of
+//     BOTH groups), A_dn (the lower ones).
+//   * a K-tile is 2 phases of 2 MI MFMAs x 2 (k halves): phase A = upper row tiles x all four column tiles (fragments: 8 B +
+//     MI A), phase B = lower row tiles (MI A fragments, the B fragments stay in registers).  4 barriers per K-tile.
+//   * load stream: B_lo, B_hi, A_up of tile kt + 2 are requested in phase B of tile kt, A_dn(kt + 1) in phase A of tile kt, so
+//     every half-tile has two phases to land; counted s_waitcnt vmcnt(N) (vmcnt retires in issue order: N = instructions
+//     issued after the half-tile that is needed), never 0 inside the loop.
+//     WAR: a wave retires its own LDS reads (lgkmcnt) BEFORE the phase's first barrier, so after any barrier every read
+//     issued before it has completed and the regions refilled next are idle.
 //   * the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one barrier apart: while one group issues its
 //     MFMAs the other issues its ds_reads / LDS-DMA, so the matrix pipe of every SIMD stays fed.
+//   * MFMA operands are swapped (C^T = B A^T) and the B rows permuted on the global side of the LDS-DMA, so a lane ends up
+//     with 8 consecutive output columns and the epilogue stores straight from registers (stage_half_perm).
+// Cycles per K-tile and workgroup (median, all CUs busy): 2 465 (MI = 8, ideal 2 048) / 2 995 (MI = 10, ideal 2 560); the
+// four-phase schedule of round 1 (8 barriers, loads 5 phases ahead) ran 2 750 / 3 200, one phase per K-tile 2 770.
 // ------------------------------------------------------------------------------------------------------
-constexpr int HT = 16384;                       // bytes of a half-tile
-constexpr int CLD2 = 256 + 4;                   // f32 row stride of the 64-row C slab staged in the epilogue
-
-__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max, int k0,
-                                           char* buf, int wave, int lane) {
-    const int L = lane * 16;
-    const int X = swz(L);
-    const int r = X >> 6, c = (X >> 4) & 3;
-    int row = row0 + wave * 16 + r;             // the wave's row-block = wave (8 row-blocks per half-tile)
-    row = row < rows_max ? row : rows_max - 1;
-    const bf16_t* src = G + (int64_t)row * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (wave * 2 + 0) * SUB), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(buf + (wave * 2 + 1) * SUB), 16, 0, 0);
-}
+constexpr int HT = 16384;                       // bytes of a B half-tile
 
 // B half-tile of the 256- / 320-row kernels: same LDS layout, but LDS row rho of sub-tile s (strip = s >> 2, j = s & 3) holds
 // the operand row  strip * 64 + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3).  With the MFMA operands swapped
@@ -272,22 +266,6 @@ __device__ __forceinline__ void stage_half_perm(const bf16_t* __restrict__ G, in
     const bf16_t* src = G + (int64_t)row * ld + k0 + c * 8;
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (wave * 2 + 0) * SUB), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_void*)(src + 32), (lds_void*)(buf + (wave * 2 + 1) * SUB), 16, 0, 0);
-}
-
-// 160-row half-tile (the 320-row tile variant): row blocks 0-7 as above, plus the four [16 x 32] sub-tiles of row blocks 8 and 9,
-// one per wave (waves 4-7 repeat what waves 0-3 load: identical bytes to identical LDS addresses, so that every wave issues the
-// same number of LDS-DMA instructions and the counted vmcnt waits stay wave-independent)
-__device__ __forceinline__ void stage_half160(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max, int k0,
-                                              char* buf, int wave, int lane) {
-    stage_half(G, ld, row0, rows_max, k0, buf, wave, lane);
-    const int L = lane * 16;
-    const int X = swz(L);
-    const int r = X >> 6, c = (X >> 4) & 3;
-    const int e = wave & 3, rb = 8 + (e >> 1), kb = e & 1;
-    int row = row0 + rb * 16 + r;
-    row = row < rows_max ? row : rows_max - 1;
-    const bf16_t* src = G + (int64_t)row * ld + k0 + kb * 32 + c * 8;
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + (rb * 2 + kb) * SUB), 16, 0, 0);
 }
 
 // A "row-half" of the two-phase schedule: the upper (dn = 0) or lower (dn = 1) RH row tiles of BOTH wave groups, written to
@@ -409,9 +387,6 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
     }
 }
 
-#ifndef DCLIP_GEMM_PHASES
-#define DCLIP_GEMM_PHASES 2
-#endif
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -455,7 +430,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#if DCLIP_GEMM_PHASES == 2
     // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_up (upper row tiles of both wave groups), 3 A_dn (lower row tiles)
     auto issue = [&](int l) {
         const int tile = l >> 2, w = l & 3;
@@ -463,16 +437,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         if (w < 2) stage_half_perm(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, lane);
         else stage_rowhalf<RH>(p.A, p.lda, m0, p.M, tile * BK, par + 2 * HT, HTA, w - 2, wave, lane);
     };
-#else
-    // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_lo, 3 A_hi
-    auto issue = [&](int l) {
-        const int tile = l >> 2, w = l & 3;
-        char* par = smem + (tile & 1) * PAR;
-        if (w < 2) stage_half_perm(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, lane);
-        else if (MI == 8) stage_half(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
-        else stage_half160(p.A, p.lda, m0 + (w - 2) * AROWS, p.M, tile * BK, par + 2 * HT + (w - 2) * HTA, wave, lane);
-    };
-#endif
     // profiling stamps (off unless dclip_trace_gemm_stamps armed them): s_memtime at start / first operands landed / main loop
     // done / epilogue done (stores acknowledged), s_memrealtime at start / end
     auto stamp = [&](int k) {
@@ -484,18 +448,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         }
     };
     stamp(0);
-#if DCLIP_GEMM_PHASES == 2
     // LDS-DMA instructions per wave: B half 2, A row-half 2 (RH = 4) or 3 (RH = 5).  vmcnt completes in issue order, so "wait
     // until half-tile X has landed" = vmcnt(number of instructions issued after X)
 #define WAIT_VM2(n8, n10) do { if (MI == 8) WAIT_VMCNT(n8); else WAIT_VMCNT(n10); } while (0)
     const int npro = nload < 7 ? nload : 7;                // tile 0 entirely, tile 1: B_lo, B_hi, A_up
     for (int l = 0; l < npro; ++l) issue(l);
     if (nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);    // B_lo, B_hi, A_up of tile 0 landed (younger: A_dn(0), B, B, A_up(1))
-#else
-    const int npro = nload < 5 ? nload : 5;
-    for (int l = 0; l < npro; ++l) issue(l);
-    if (nload > 4) WAIT_VMCNT(2); else WAIT_VMCNT(0);      // the youngest half-tile in flight is always a B half: 2 instructions
-#endif
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
@@ -505,9 +463,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
     bf16x8 af[RH][2], b0[2][2], b1[2][2];
 
-#if DCLIP_GEMM_PHASES == 2
     // Two phases per K-tile: A = upper row tiles of the wave x all four column tiles, B = lower row tiles.  MFMA clusters of
-    // 4 RH instructions between barriers, 4 barriers per K-tile (the four-phase schedule kept under DCLIP_GEMM_PHASES=4 has 8).
+    // 4 RH instructions between barriers, 4 barriers per K-tile.
     // Load stream: the operands of phase A of tile kt + 1 (B_lo, B_hi, A_up) are requested in phase B of tile kt - 1, A_dn(kt + 1)
     // in phase A of tile kt: every half-tile has two full phases (~2.5 k cycles) to land, which is what the loop needs when all
     // 256 CUs pull operands at once (with one phase of slack the same loop stalled on vmcnt: 3 200 instead of 2 480 cycles per
@@ -575,87 +532,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
-#else
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* base = smem + (kt & 1) * PAR;
-        const char* ap = base + a_off + fragoff;
-        const char* bp = base + b_off + fragoff;
-        const int k4 = kt * 4;
-        // ---------------- phase 0 : quadrant (upper rows, cols 0-31) ----------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) b0[j][kb] = *(const bf16x8*)(bp + (j * 2 + kb) * SUB);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < RH; ++i)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + (i * 2 + kb) * SUB);
-        if (k4 + 5 < nload) issue(k4 + 5);
-        __builtin_amdgcn_s_barrier();
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < RH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- phase 1 : quadrant (upper rows, cols 32-63) ----------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) b1[j][kb] = *(const bf16x8*)(bp + ((2 + j) * 2 + kb) * SUB);
-        if (k4 + 6 < nload) issue(k4 + 6);
-        __builtin_amdgcn_s_barrier();
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < RH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- phase 2 : quadrant (lower rows, cols 32-63) ----------------
-#pragma unroll
-        for (int i = 0; i < RH; ++i)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) af[i][kb] = *(const bf16x8*)(ap + ((RH + i) * 2 + kb) * SUB);
-        if (k4 + 7 < nload) issue(k4 + 7);
-        __builtin_amdgcn_s_barrier();
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < RH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[RH + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[RH + i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- phase 3 : quadrant (lower rows, cols 0-31) ----------------
-        if (k4 + 8 < nload) { issue(k4 + 8); WAIT_VMCNT(2); }
-        else WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < RH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[RH + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-    }
-#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
     stamp(2);
 
