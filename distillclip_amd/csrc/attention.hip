@@ -869,6 +869,7 @@ struct SoftmaxBwd {
     float* dWl;              // [H,H] += (may be null)
     float* dWw;
     int B, N, Np;
+    unsigned long long* stamps;   // profiling only (dclip_trace_attn_stamps): 8 x u64 per (wave, row iteration < 4), else null
 };
 
 // Head-mixing softmax backward, everything matrix-shaped on v_mfma_f32_32x32x16_bf16 (one wave per (b, query row)):
@@ -935,10 +936,18 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
     };
     const int row_first = blockIdx.x * 4 + wave, row_step = gridDim.x * 4;
     if (PREFETCH && row_first < rows) fetch(row_first);
-    for (int row = row_first; row < rows; row += row_step) {
+    int iter = 0;
+    auto stamp = [&](int k) {
+        if (p.stamps && lane == 0 && iter < 4) {
+            if (k == 1 || k == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            p.stamps[(((int64_t)blockIdx.x * 4 + wave) * 4 + iter) * 8 + k] = __builtin_readcyclecounter();
+        }
+    };
+    for (int row = row_first; row < rows; row += row_step, ++iter) {
         const int b = row / p.N, i = row % p.N;
         const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
         __builtin_amdgcn_wave_barrier();
+        stamp(0);
         if (PREFETCH) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -971,6 +980,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
         if (PREFETCH && row + row_step < rows) fetch(row + row_step);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        stamp(1);
         // Cw = dR P^T  (this row's dW_w contribution) and the softmax row sums rs[h] = sum_g Ww[g,h] Cw[g,h]
         float part = 0.f;
         {
@@ -992,6 +1002,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
             const int h0 = (r & 3) + 8 * (r >> 2);
             rsr[r] = hh ? lane_bcast(part, h0 + 4) : lane_bcast(part, h0);
         }
+        stamp(2);
         // one key tile at a time: dP = Ww^T dR, P in accumulator layout, dA = P o (dP - rs), dS = Wl^T dA
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -1027,6 +1038,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
             }
         }
         // dW_l += dA S^T
+        stamp(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1035,6 +1047,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
                 const int off = c * ROWB + (ks * 16 + hh * 8) * 2;
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tD + off), *(const bf16x8*)(tS + off), accl, 0, 0, 0);
             }
+        stamp(4);
     }
     // accumulators: element (g = (r&3) + 8*(r>>2) + 4*hh, h = c)
 #pragma unroll
@@ -1076,6 +1089,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_plain_kernel(SoftmaxBwd 
     }
 }
 
+unsigned long long* g_attn_stamps = nullptr;
+
 int check_mm(const AttnMM& p, const char* who) {
     DCLIP_REQUIRE(p.A && p.Bm && p.C, "%s: null operand", who);
     DCLIP_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.N <= NMAX, "%s: need 0 < N <= %d (N=%d)", who, NMAX, p.N);
@@ -1085,6 +1100,8 @@ int check_mm(const AttnMM& p, const char* who) {
 }
 
 }  // namespace
+
+extern "C" int dclip_trace_attn_stamps(void* buf) { g_attn_stamps = (unsigned long long*)buf; return 0; }
 
 extern "C" int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B,
                              int64_t H, int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
@@ -1211,7 +1228,7 @@ extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const void*
     DCLIP_REQUIRE(dR && P && dS && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_softmax_bwd: bad argument");
     DCLIP_REQUIRE((Wl == nullptr) == (Ww == nullptr), "dclip_attn_softmax_bwd: conv_l and conv_w come together");
     DCLIP_REQUIRE(!Wl || S, "dclip_attn_softmax_bwd: raw scores needed for dW_l");
-    SoftmaxBwd p{(const bf16_t*)dR, (const bf16_t*)P, (const float*)S, scores_bf16, Wl, Ww, (bf16_t*)dS, dWl, dWw, (int)B, (int)N, (int)Np};
+    SoftmaxBwd p{(const bf16_t*)dR, (const bf16_t*)P, (const float*)S, scores_bf16, Wl, Ww, (bf16_t*)dS, dWl, dWw, (int)B, (int)N, (int)Np, g_attn_stamps};
     TraceScope tr(DCLIP_TRACE_ATTN, Wl ? 8.0 * B * H * H * N * N : 0.0, (2.0 + 2.0 + 2.0 + (Wl ? (scores_bf16 ? 2.0 : 4.0) : 0.0)) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)H, 6);
     int blocks = (int)((B * N + 3) / 4);
     if (blocks > 2048) blocks = 2048;

@@ -361,6 +361,9 @@ int64_t dclip_trace_dims(int32_t* dims, int64_t cap);
  * uint64 stamps to buf[6 * workgroup ..]: s_memtime at start / first operands landed / main loop done / epilogue done, then
  * s_memrealtime (100 MHz) at start / end (tools/diag/gemm_phases.py).  NULL switches it off. */
 int dclip_trace_gemm_stamps(void* buf);
+/* same for the head-mixing softmax backward: 8 uint64 per (wave, row iteration < 4): s_memtime at row start / operands in LDS /
+ * row sums done / key tiles done / dW_l done (tools/diag/attn_phases.py) */
+int dclip_trace_attn_stamps(void* buf);
 
 #ifdef __cplusplus
 }
