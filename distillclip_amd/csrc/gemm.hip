@@ -34,7 +34,6 @@ struct GemmNT {
     int row_group; const float* rowadd;
     float* colsum;                                  // += column sums of the epilogue output (bias gradient), may be null
     int tiles_m, tiles_n;
-    int preload;                                    // epilogue: fetch residual / aux rows of a slab ahead of its LDS staging
     unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps): 6 x u64 per workgroup, else null
     int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
 };
@@ -1130,8 +1129,6 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.residual = residual; p.ldr = ldr;
     p.row_group = (int)row_group; p.rowadd = rowadd; p.colsum = colsum_acc;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
-    static const int epi_preload = [] { const char* e = getenv("DCLIP_EPI_PRELOAD"); return e ? atoi(e) : 1; }();
-    p.preload = epi_preload;
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
     hipStream_t st = (hipStream_t)stream;
