@@ -612,6 +612,7 @@ struct GemmTN {
     float* out; int64_t ldo;
     int M, P, Q;
     int tiles_p, tiles_q, splits, chunk;            // chunk = rows of M per split (multiple of TC)
+    unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps), else null
 };
 
 // load a [64 x 128] bf16 tile (rows m0.., cols c0..) into registers: 4 x 16 B per thread
@@ -877,6 +878,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         if (w < 2) stage_half_tn(p.B, p.ldb, m_begin + kt * TC, q0 + w * 128, buf, wave, lane);
         else stage_half_tn(p.A, p.lda, m_begin + kt * TC, p0 + (w - 2) * 128, buf, wave, lane);
     };
+    auto stamp = [&](int k) {
+        if (p.stamps && tid == 0) {
+            if (k == 3) WAIT_VMCNT(0);
+            p.stamps[6 * (int64_t)blockIdx.x + k] = __builtin_readcyclecounter();
+            if (k == 0) p.stamps[6 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+            if (k == 3) p.stamps[6 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
     // Two phases per contraction chunk (rows 0-63 / 64-127 of the wave's 128 output rows x its 64 columns), as in
     // gemm_nt256_kernel: 4 barriers per chunk, MFMA clusters of 32.  Loads run 6 half-tiles ahead (the A halves of chunk kt + 1
     // are requested in phase A of chunk kt, the B halves of chunk kt + 2 in phase B); a wave retires its own LDS reads before
@@ -885,6 +895,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
     for (int l = 0; l < npro; ++l) issue(l);
     if (nload > 4) WAIT_VMCNT(4); else WAIT_VMCNT(0);      // (two B halves of chunk 1 stay in flight: 2 instructions each)
     __builtin_amdgcn_s_barrier();
+    stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
     const int a_off = (2 + wr) * HT;
@@ -953,6 +964,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    stamp(2);
 
     // epilogue: 4 slabs of 64 rows through LDS, then row-contiguous f32 atomics (256 lanes x 4 B = 1 KiB per row)
     float* cs = (float*)smem;
@@ -976,6 +988,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
             unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, cs[sl * CL + (tid & 255)]);
         }
     }
+    stamp(3);
 }
 
 // column sums: grid (ceil(N/256) , row_splits); each thread owns one column, strides rows
@@ -1155,7 +1168,7 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     DCLIP_REQUIRE(splits >= 1, "dclip_gemm_tn_acc: splits must be >= 1");
     GemmTN p;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.out = dW; p.ldo = ldo;
-    p.M = (int)M; p.P = (int)P; p.Q = (int)Q;
+    p.M = (int)M; p.P = (int)P; p.Q = (int)Q; p.stamps = g_gemm_stamps;
     p.tiles_p = (int)((P + TP - 1) / TP); p.tiles_q = (int)((Q + TQ - 1) / TQ);
     int chunk = (int)((M + splits - 1) / splits);
     chunk = ((chunk + TC - 1) / TC) * TC;
