@@ -767,9 +767,11 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wq = wave & 1;
 
-    int t = blockIdx.x;
-    const int split = t % p.splits; t /= p.splits;
-    const int tq = t % p.tiles_q, tp = t / p.tiles_q;
+    // split-major order cut into one chunk per XCD, as in gemm_tn256_kernel: co-resident workgroups of an XCD share operand slices
+    const int tiles = p.tiles_p * p.tiles_q;
+    const int t = xcd_remap(blockIdx.x, tiles * p.splits);
+    const int split = t / tiles, tile = t - split * tiles;
+    const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
     const int p0 = tp * TP, q0 = tq * TQ;
     const int m_begin = split * p.chunk;
     const int m_end = min(p.M, m_begin + p.chunk);
