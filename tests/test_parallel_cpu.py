@@ -16,6 +16,37 @@ def _free_port():
     return p
 
 
+def _run_ranks(target, world=2, timeout=120, attempts=2):
+    """spawn `world` rank processes of `target(rank, world, port, q)` and collect one queue item per rank.  The rendezvous port
+    comes from bind-then-close, which another process can grab in between: one retry on a fresh port covers that race."""
+    import queue as _queue
+    ctx = mp.get_context('spawn')
+    last = None
+    for _ in range(attempts):
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        try:
+            res = [q.get(timeout=timeout) for _ in ps]
+        except _queue.Empty as e:
+            last = e
+            for p in ps:
+                if p.is_alive():
+                    p.terminate()
+                p.join(timeout=30)
+            continue
+        codes = []
+        for p in ps:
+            p.join(timeout=60)
+            codes.append(p.exitcode)
+        if all(c == 0 for c in codes):
+            return res
+        last = AssertionError(f'rank exit codes {codes}')
+    raise last
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -32,16 +63,7 @@ def _worker(rank, world, port, q):
 
 
 def test_grad_sync_averages_flat_buffers_world2():
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, 2, timeout=120)
     want_g = torch.arange(3333, dtype=torch.float32) * 1.5
     for _, g, h in res:
         assert torch.allclose(g, want_g) and torch.allclose(h, torch.full((17,), 0.5))
@@ -61,16 +83,7 @@ def _gather_worker(rank, world, port, q):
 
 def test_gather_embeddings_world2():
     """global-negative mode plumbing: one fused all-gather, rank-major row order, shard slice = own rows"""
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_gather_worker, 2, timeout=120)
     for rank, r, w, ga, gb in res:
         assert (r, w) == (rank, 2) and ga.shape == (6, 4) and gb.shape == (6, 2)
         assert torch.equal(ga[:3], torch.zeros(3, 4) + torch.arange(4)) and torch.equal(ga[3:], torch.ones(3, 4) + torch.arange(4))
@@ -139,16 +152,7 @@ def _gather_rows_worker(rank, world, port, q):
 def test_validation_gather_rows_world2():
     """validation_step's all_gather of the representations (reference dual_distill_model.py:141-146): rank-major rows,
     identical on every rank, so each rank's validation_epoch_end sees the whole validation set"""
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_gather_rows_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_gather_rows_worker, 2, timeout=120)
     base = torch.arange(6, dtype=torch.float32).reshape(3, 2)
     for _, g in res:
         assert torch.equal(g, torch.cat([base, base + 100]))
@@ -241,17 +245,8 @@ def _sharded_worker(rank, world, port, q):
 
 
 def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded_world2():
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
     world = 2
-    ps = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=90) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_sharded_worker, world, timeout=90)
     # expected: torch.optim.AdamW on the AVERAGED gradients, trainable entries only (what DDP + the reference's optimizer do)
     ref = _FakeTower(_TOTAL, _BUCKETS, _TRAINABLE, seed=3)
     mask = torch.zeros(_TOTAL, dtype=torch.bool)
@@ -327,14 +322,5 @@ def _ragged_worker(rank, world, port, q):
 
 
 def test_global_negatives_reject_unequal_batches_on_every_rank():
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=90) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_ragged_worker, 2, timeout=90)
     assert all('same per-rank batch' in msg and '7..8' in msg for _, msg in res), res
