@@ -552,47 +552,58 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             bias[jp][4] = q1.x; bias[jp][5] = q1.y; bias[jp][6] = q1.z; bias[jp][7] = q1.w;
         }
     }
-    // units u = 2 i + jp in a ring of NB side buffers: the loads of unit u + NB - 1 are in flight while unit u is computed and
-    // stored (the fragment registers of the main loop are dead here, which pays for the ring)
+    // units u = 2 i + jp, processed in batches of BU: a batch's side operands are all requested before its first store.  vmcnt
+    // retires loads and stores in ONE in-order queue, so a load issued after a store cannot be waited for without also waiting
+    // for that store's acknowledgement — a ring that refills one slot per unit (loads interleaved with stores) turned the
+    // MULAUX epilogue into a chain of write round trips (58 k cycles per 320 x 256 tile).  With batches the wave pays that
+    // once per batch boundary: none at all where the side operands of the whole tile fit the registers the dead fragments free.
     constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
-    constexpr int NB = !SIDE ? 1 : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : 6)) : 8);
     constexpr int NU = 2 * MI;
-    EpiSide side[NB];
+    constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : 5)) : (MI == 8 ? 16 : 10));
+    static_assert(NU % BU == 0, "batch size must divide the unit count");
+    EpiSide side[SIDE ? BU : 1];
     const int row0 = m0 + wr * AROWS + rl;
     const int64_t o0 = (int64_t)row0 * p.ldc + colb, r0off = (int64_t)row0 * p.ldr + colb;
     const int64_t ostep = 16 * p.ldc, rstep = 16 * p.ldr;
-    auto load_side = [&](int u, EpiSide& sd) {
-        const int i = u >> 1, jp = u & 1;
-        if (row0 + i * 16 < p.M && colb + jp * 32 < p.N) epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, sd);
-    };
-    if (SIDE) {
 #pragma unroll
-        for (int u = 0; u < NB - 1 && u < NU; ++u) load_side(u, side[u % NB]);
-    }
+    for (int ub = 0; ub < NU; ub += BU) {
+        if (SIDE) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = u >> 1, jp = u & 1;
-        if (SIDE && u + NB - 1 < NU) load_side(u + NB - 1, side[(u + NB - 1) % NB]);
-        const int row = row0 + i * 16, col = colb + jp * 32;
-        if (row < p.M && col < p.N) {
-            float v[8];
+            for (int u = ub; u < ub + BU; ++u) {
+                const int i = u >> 1, jp = u & 1;
+                if (row0 + i * 16 < p.M && colb + jp * 32 < p.N)
+                    epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
+            }
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-            epilogue_vec8<ACT, OUT_F32>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
-                                        side[SIDE ? u % NB : 0]);
+        for (int u = ub; u < ub + BU; ++u) {
+            const int i = u >> 1, jp = u & 1;
+            const int row = row0 + i * 16, col = colb + jp * 32;
+            if (row < p.M && col < p.N) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                epilogue_vec8<ACT, OUT_F32>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                                            side[SIDE ? u - ub : 0]);
+            }
         }
     }
     if (!OUT_F32 && p.colsum) {     // (f32 output + column sums: launch_nt routes that combination to the 128^2 kernel)
+        // 16-lane shuffle reduce, then the 8 waves combine through LDS (idle since the main loop's last barrier) so that the
+        // workgroup issues 4 atomic wave-instructions for its 256 columns: the chip retires about one atomic wave-instruction per
+        // 50 ns and CU whatever its width, and 16 four-lane atomics per wave (128 per tile) cost the MULAUX dgrad 60 us per launch
+        float* cs = (float*)smem;                   // [2 wave groups][256 columns]
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            const int col = colb + jp * 32;
+        for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = csum[jp][e];
                 x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
-                if (rl == 0 && col < p.N) unsafeAtomicAdd(p.colsum + col + e, x);
+                if (rl == 0) cs[wr * 256 + wc * 64 + jp * 32 + g * 8 + e] = x;
             }
-        }
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (tid < 256 && n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, cs[tid] + cs[256 + tid]);
     }
     stamp(3);
 }
