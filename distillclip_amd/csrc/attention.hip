@@ -60,41 +60,41 @@ __global__ __launch_bounds__(256) void attn_nt_kernel(AttnMM p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bfr[jt][ks] = *(const bf16x8*)(Bm + (int64_t)jb * p.ldb + ks * 32 + fk);
         }
-    bf16x8 af[KS], afn[KS];
-    {
-        const int ia = min(fr, p.N - 1);
+    // every query-tile fragment is requested before the first store: vmcnt retires loads and stores in one in-order queue, so a
+    // load issued after a store cannot be waited for without waiting for that store's acknowledgement as well
+    bf16x8 afa[NTM][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
-    }
-    for (int it = 0; it < nt; ++it) {
-        if (it + 1 < nt) {                               // prefetch the next query tile under this tile's MFMAs / stores
-            const int ia = min((it + 1) * 16 + fr, p.N - 1);
+    for (int it = 0; it < NTM; ++it)
+        if (it < nt) {
+            const int ia = min(it * 16 + fr, p.N - 1);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) afn[ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
+            for (int ks = 0; ks < KS; ++ks) afa[it][ks] = *(const bf16x8*)(A + (int64_t)ia * p.lda + ks * 32 + fk);
         }
 #pragma unroll
-        for (int jt = 0; jt < NTM; ++jt) {
-            if (jt < nt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < NTM; ++it) {
+        if (it < nt) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr[jt][ks], acc, 0, 0, 0);
-                const int j = jt * 16 + fr;
-                if (j < p.Np) {
+            for (int jt = 0; jt < NTM; ++jt) {
+                if (jt < nt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = it * 16 + (lane >> 4) * 4 + r;
-                        if (i < p.N) {
-                            const float v = j < p.N ? acc[r] * p.alpha : 0.f;
-                            const int64_t o = (((int64_t)b * p.H + h) * p.N + i) * p.ldc + j;
-                            if (OUT_F32) ((float*)p.C)[o] = v;
-                            else ((bf16_t*)p.C)[o] = f2bf(v);
+                    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afa[it][ks], bfr[jt][ks], acc, 0, 0, 0);
+                    const int j = jt * 16 + fr;
+                    if (j < p.Np) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = it * 16 + (lane >> 4) * 4 + r;
+                            if (i < p.N) {
+                                const float v = j < p.N ? acc[r] * p.alpha : 0.f;
+                                const int64_t o = (((int64_t)b * p.H + h) * p.N + i) * p.ldc + j;
+                                if (OUT_F32) ((float*)p.C)[o] = v;
+                                else ((bf16_t*)p.C)[o] = f2bf(v);
+                            }
                         }
                     }
                 }
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = afn[ks];
     }
 }
 
