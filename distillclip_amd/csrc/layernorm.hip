@@ -77,68 +77,93 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const int c = (i * 64 + lane) * 4;
         gm[i] = c < D ? *(const float4*)(gamma + c) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    // two rows per iteration: the loads of the second row are in flight while the first row's reductions run
+    // Software pipeline over rows: the loads of the NEXT row are issued before the stores of the current one.  vmcnt retires
+    // loads and stores in one in-order queue, so a row whose loads follow the previous row's stores (the round-1 loop: load two
+    // rows, reduce, store two rows, repeat) cannot start before those stores are acknowledged.
+    struct Raw {
+        float4 x[NV], a[NV], d[NV];
+        float mu, rs;
+        int64_t src;
+        int row;
+    };
+    auto issue = [&](int row, Raw& r) {
+        r.row = row;
+        r.src = ridx ? ridx[row] : row;
+        r.mu = mean[row];
+        r.rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            r.x[i] = r.a[i] = r.d[i] = float4{0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                r.x[i] = *(const float4*)(x + r.src * ldx + c);
+                r.a[i] = *(const float4*)(dx_acc + r.src * lddx + c);
+                if (DY_F32) r.d[i] = *(const float4*)((const float*)dy + (int64_t)row * lddy + c);
+                else {
+                    const bf16x4 t = *(const bf16x4*)((const bf16_t*)dy + (int64_t)row * lddy + c);
+                    union { bf16x4 h; float2 f; } u; u.h = t;
+                    r.d[i].x = u.f.x; r.d[i].y = u.f.y;            // raw bits, expanded in process()
+                }
+            }
+        }
+    };
+    auto process = [&](const Raw& r) {
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            xh[i] = g[i] = float4{0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                float4 d;
+                if (DY_F32) d = r.d[i];
+                else {
+                    union { bf16x4 h; float2 f; } u; u.f = float2{r.d[i].x, r.d[i].y};
+                    d = float4{bf2f(u.h[0]), bf2f(u.h[1]), bf2f(u.h[2]), bf2f(u.h[3])};
+                }
+                const float4 xv = r.x[i];
+                xh[i] = float4{(xv.x - r.mu) * r.rs, (xv.y - r.mu) * r.rs, (xv.z - r.mu) * r.rs, (xv.w - r.mu) * r.rs};
+                g[i] = float4{d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w};
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+                db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                float* o = dx_acc + r.src * lddx + c;
+                float4 a = r.a[i];
+                a.x += r.rs * (g[i].x - c1 - xh[i].x * c2);
+                a.y += r.rs * (g[i].y - c1 - xh[i].y * c2);
+                a.z += r.rs * (g[i].z - c1 - xh[i].z * c2);
+                a.w += r.rs * (g[i].w - c1 - xh[i].w * c2);
+                *(float4*)o = a;
+                cs[i].x += a.x; cs[i].y += a.y; cs[i].z += a.z; cs[i].w += a.w;
+                if (dx_bf16) {
+                    bf16x4 bq = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+                    *(bf16x4*)(dx_bf16 + r.src * lddb + c) = bq;
+                }
+            }
+        }
+    };
     const int stride = gridDim.x * 4;
-    for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
-        const int rowv[2] = {row0, row0 + stride};
-        float4 xh[2][NV], g[2][NV], ain[2][NV];
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2];
-        int64_t srcv[2];
-        bool ok[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ok[u] = rowv[u] < M;
-            const int row = ok[u] ? rowv[u] : row0;
-            srcv[u] = ridx ? ridx[row] : row;
-            const float mu = mean[row];
-            rsv[u] = rstd[row];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                xh[u][i] = g[u][i] = ain[u][i] = float4{0.f, 0.f, 0.f, 0.f};
-                if (c < D && ok[u]) {
-                    const float4 xv = *(const float4*)(x + srcv[u] * ldx + c);
-                    ain[u][i] = *(const float4*)(dx_acc + srcv[u] * lddx + c);      // issued with the other loads, consumed after the reductions
-                    float4 d;
-                    if (DY_F32) d = *(const float4*)((const float*)dy + (int64_t)row * lddy + c);
-                    else {
-                        const bf16x4 t = *(const bf16x4*)((const bf16_t*)dy + (int64_t)row * lddy + c);
-                        d = float4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
-                    }
-                    const float rs = rsv[u];
-                    xh[u][i] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
-                    g[u][i] = float4{d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w};
-                    s1[u] += (g[u][i].x + g[u][i].y) + (g[u][i].z + g[u][i].w);
-                    s2[u] += (g[u][i].x * xh[u][i].x + g[u][i].y * xh[u][i].y) + (g[u][i].z * xh[u][i].z + g[u][i].w * xh[u][i].w);
-                    dg[i].x += d.x * xh[u][i].x; dg[i].y += d.y * xh[u][i].y; dg[i].z += d.z * xh[u][i].z; dg[i].w += d.w * xh[u][i].w;
-                    db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float c1 = wave_sum(s1[u]) / D, c2 = wave_sum(s2[u]) / D;
-            if (!ok[u]) continue;
-            const float rs = rsv[u];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                if (c < D) {
-                    float* o = dx_acc + srcv[u] * lddx + c;
-                    float4 a = ain[u][i];
-                    a.x += rs * (g[u][i].x - c1 - xh[u][i].x * c2);
-                    a.y += rs * (g[u][i].y - c1 - xh[u][i].y * c2);
-                    a.z += rs * (g[u][i].z - c1 - xh[u][i].z * c2);
-                    a.w += rs * (g[u][i].w - c1 - xh[u][i].w * c2);
-                    *(float4*)o = a;
-                    cs[i].x += a.x; cs[i].y += a.y; cs[i].z += a.z; cs[i].w += a.w;
-                    if (dx_bf16) {
-                        bf16x4 bq = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
-                        *(bf16x4*)(dx_bf16 + srcv[u] * lddb + c) = bq;
-                    }
-                }
-            }
-        }
+    Raw ra, rb;
+    int row = blockIdx.x * 4 + wave;
+    if (row < M) issue(row, ra);
+    while (row < M) {
+        int nrow = row + stride;
+        if (nrow < M) issue(nrow, rb);
+        process(ra);
+        row = nrow;
+        if (row >= M) break;
+        nrow = row + stride;
+        if (nrow < M) issue(nrow, ra);
+        process(rb);
+        row = nrow;
     }
     // block reduction of the parameter gradients, then one atomic per column per block
 #pragma unroll
