@@ -943,12 +943,31 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
             p.stamps[(((int64_t)blockIdx.x * 4 + wave) * 4 + iter) * 8 + k] = __builtin_readcyclecounter();
         }
     };
+    // dS of a row is staged in the dR tile (each key tile's columns are dead once its dP product has been read) and leaves as
+    // 16-byte row segments at the START of the next iteration, after that row's loads have been issued: vmcnt retires loads and
+    // stores in one in-order queue, so the 32 scattered 2-byte stores per row of the first version, issued before the next
+    // row's loads, made every row wait for their acknowledgement.
+    int64_t prev_base = -1;
+    auto flush = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + it * 64;
+            if (idx < total) {
+                const int h = idx / nchunk, ck = idx - h * nchunk;
+                *(u32x4*)(p.dS + prev_base + h * hs + ck * 8) = *(const u32x4*)(tR + h * ROWB + ck * 16);
+            }
+        }
+    };
     for (int row = row_first; row < rows; row += row_step, ++iter) {
         const int b = row / p.N, i = row % p.N;
         const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
         __builtin_amdgcn_wave_barrier();
         stamp(0);
-        if (PREFETCH) {
+        if (!PREFETCH) fetch(row);                       // loads first ...
+        if (prev_base >= 0) flush();                     // ... then the previous row's stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = lane + it * 64;
@@ -962,21 +981,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
                                                                       f2bf(s1.x), f2bf(s1.y), f2bf(s1.z), f2bf(s1.w)};
                 }
             }
-        } else {
-            for (int idx = lane; idx < total; idx += 64) {
-                const int h = idx / nchunk, ck = idx - h * nchunk;
-                const int64_t src = base + h * hs + ck * 8;
-                *(u32x4*)(tR + h * ROWB + ck * 16) = *(const u32x4*)(p.dR + src);
-                *(u32x4*)(tP + h * ROWB + ck * 16) = *(const u32x4*)(p.P + src);
-                if (p.s_bf16) {
-                    *(u32x4*)(tS + h * ROWB + ck * 16) = *(const u32x4*)((const bf16_t*)p.S + src);
-                } else {
-                    const float4 s0 = *(const float4*)(p.S + src), s1 = *(const float4*)(p.S + src + 4);
-                    *(bf16x8*)(tS + h * ROWB + ck * 16) = bf16x8{f2bf(s0.x), f2bf(s0.y), f2bf(s0.z), f2bf(s0.w),
-                                                                 f2bf(s1.x), f2bf(s1.y), f2bf(s1.z), f2bf(s1.w)};
-                }
-            }
         }
+        prev_base = base;
         if (PREFETCH && row + row_step < rows) fetch(row + row_step);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1027,13 +1033,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
                     for (int e = 0; e < 8; ++e) bf[e] = f2bf(dp[8 * s + e]);
                     ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf, ds, 0, 0, 0);
                 }
-                const int j = 32 * ct + c;
-                if (j < p.Np) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (h < H) p.dS[base + h * hs + j] = f2bf(ds[r]);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (h < H) *(bf16_t*)(tR + h * ROWB + (32 * ct + c) * 2) = f2bf(ds[r]);      // this key tile's dR columns are dead
                 }
             }
         }
@@ -1049,13 +1052,36 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
             }
         stamp(4);
     }
-    // accumulators: element (g = (r&3) + 8*(r>>2) + 4*hh, h = c)
+    if (prev_base >= 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        flush();
+    }
+    // accumulators: element (g = (r&3) + 8*(r>>2) + 4*hh, h = c).  The 2 H^2 gradient elements live in ~36 cache lines that every
+    // wave of the grid adds to: the workgroup's four waves are summed through LDS first (the tiles are dead) so that one wave
+    // issues the atomics — same-line atomics serialise, and with 2 048 waves adding they were ~half of the kernel's time.
+    __syncthreads();
+    float* red = (float*)smem;                          // [4 waves][2][16][64]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (g < H && c < H) {
-            if (p.dWw) unsafeAtomicAdd(p.dWw + g * H + c, accw[r]);
-            if (p.dWl) unsafeAtomicAdd(p.dWl + g * H + c, accl[r]);
+        red[((wave * 2 + 0) * 16 + r) * 64 + lane] = accw[r];
+        red[((wave * 2 + 1) * 16 + r) * 64 + lane] = accl[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int g = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (g < H && c < H) {
+                float w = 0.f, l = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    w += red[((v * 2 + 0) * 16 + r) * 64 + lane];
+                    l += red[((v * 2 + 1) * 16 + r) * 64 + lane];
+                }
+                if (p.dWw) unsafeAtomicAdd(p.dWw + g * H + c, w);
+                if (p.dWl) unsafeAtomicAdd(p.dWl + g * H + c, l);
+            }
         }
     }
 }
