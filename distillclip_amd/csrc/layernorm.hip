@@ -62,13 +62,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // backward: dx_acc[row] += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //           dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy       (per-wave register partials -> LDS -> atomics)
 template <int NV, bool DY_F32>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                      int64_t ldx, const int* __restrict__ ridx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx_acc,
                                                      int64_t lddx, bf16_t* __restrict__ dx_bf16, int64_t lddb,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ colsum, int M, int D) {
-    __shared__ float red[3][4][LN_MAXV * 256];
+    // 8 waves per block (the register budget allows 2 waves per SIMD = one such block per CU): the block's parameter-gradient
+    // partials are summed through LDS and leave as ONE set of 3 D atomics — all blocks add to the same 3 D / 32 cache lines, and
+    // same-line atomics serialise (4-wave blocks spent 10-17 % of the kernel there: tools/diag/ln_bench.py with the atomics off)
+    constexpr int NW = 8, DP = NV * 256;
+    extern __shared__ float red_[];                      // [3][NW][DP]
+    float (*red)[NW][DP] = (float (*)[NW][DP])red_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dg[NV], db[NV], gm[NV], cs[NV];
 #pragma unroll
@@ -150,9 +155,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     };
-    const int stride = gridDim.x * 4;
+    const int stride = gridDim.x * NW;
     Raw ra, rb;
-    int row = blockIdx.x * 4 + wave;
+    int row = blockIdx.x * NW + wave;
     if (row < M) issue(row, ra);
     while (row < M) {
         int nrow = row + stride;
@@ -174,12 +179,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         *(float4*)&red[2][wave][c] = cs[i];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    for (int c = threadIdx.x; c < D; c += 64 * NW) {
+        float a = 0.f, b = 0.f, k = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a += red[0][w][c]; b += red[1][w][c]; k += red[2][w][c]; }
         if (dgamma) unsafeAtomicAdd(dgamma + c, a);
         if (dbeta) unsafeAtomicAdd(dbeta + c, b);
-        if (colsum) unsafeAtomicAdd(colsum + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+        if (colsum) unsafeAtomicAdd(colsum + c, k);
     }
 }
 
@@ -216,20 +222,17 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
     DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx_acc, "dclip_layernorm_bwd: null operand");
     DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
     const int nv = (int)((D + 255) / 256);
-    // persistent grid: every block ends with 3 x D float atomics (dgamma, dbeta, column sums), so the block count trades
-    // bytes in flight against atomic traffic.  Measured (tools/diag/ln_bench.py, sustained, 25600 / 39424 rows x 768): 1024 blocks
-    // 4.99 / 4.49 TB/s, 768 blocks 5.33 / 5.41, 512 blocks 5.67 / 5.03, 256 blocks 5.08 / 3.31 -> ~12 rows of 768 per wave.
-    int blocks = (int)((M + 3) / 4);
+    // persistent grid of 8-wave blocks, one per CU (the kernel's registers allow 2 waves per SIMD): every block ends with 3 x D
+    // float atomics onto the same 3 D / 32 cache lines, so fewer, fatter blocks are cheaper — as long as every CU has one
+    int blocks = (int)((M + 7) / 8);
     static const int force_blocks = [] { const char* e = getenv("DCLIP_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
-    int want = (int)(((double)M * (double)D / (4.0 * 12.0 * 768.0) + 128.0) / 256.0) * 256;
-    want = want < 256 ? 256 : (want > 1024 ? 1024 : want);
-    if (force_blocks > 0) want = force_blocks;
+    const int want = force_blocks > 0 ? force_blocks : 256;
     if (blocks > want) blocks = want;
     // algorithmic bytes: read dy (2 or 4), x (4), dx_acc (4) ; write dx_acc (4) + optional bf16 copy (2)
     TraceScope tr(DCLIP_TRACE_LN_BWD, 12.0 * (double)M * D, (double)M * D * ((dy_f32 ? 4.0 : 2.0) + 12.0 + (dx_bf16 ? 2.0 : 0.0)), stream, (int)M, (int)D, 0, 0);
     hipStream_t st = (hipStream_t)stream;
     LN_DISPATCH(nv,
-        if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D);
-        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D));
+        if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(512), (size_t)3 * 8 * NV * 256 * 4, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(512), (size_t)3 * 8 * NV * 256 * 4, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D));
     return dclip_check_launch("dclip_layernorm_bwd");
 }
