@@ -21,6 +21,10 @@ constexpr int SC_IMG = 0;      // +0 l1  +1 cos  +2 kl  +3 ce        (raw sums, 
 constexpr int SC_TXT = 4;
 constexpr int SC_POS = 8, SC_NEG = 9, SC_MSE = 10, SC_DIAG = 11, SC_KL0 = 12, SC_KL1 = 13, SC_LSE0 = 14, SC_LSE1 = 15;
 constexpr int NSC = 16;
+// The scalar accumulators are replicated: every wave adds to the copy picked by its block / wave index, loss_total_kernel sums
+// the copies.  All of them in ONE cache line meant ~2 000 (row kernel) / ~4 000 (stripe kernel) serialised same-line atomics:
+// 33 and 67 us of kernels whose work is a few microseconds, on the step's critical path between forward and backward.
+constexpr int NREP = 64, SCSTRIDE = 32;                     // 64 copies, one 128-byte line each
 
 struct LossCfg {
     float w_l1, w_cos, w_kl, w_ce;            // tower terms: scale * percent
@@ -47,6 +51,12 @@ struct LossArgs {
                                               // data-parallel ranks evaluate their own row block of the global-negative loss
     LossCfg c;
 };
+
+__device__ __forceinline__ float* scal_slot(const LossArgs& a) {
+    const unsigned r = (blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z + 7u * (threadIdx.x >> 6)) % NREP;
+    return a.scal + r * SCSTRIDE;
+}
+
 
 // -------------------------------------------------------------------------------------------------------------
 // kernel 1: one wave per sample: tower terms (+ their gradients) and the normalised embeddings
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
         }
         kl = wave_sum(kl); ce = wave_sum(ce);
         if (lane == 0 && own) {
-            float* sc = a.scal + (tow ? SC_TXT : SC_IMG);
+            float* sc = scal_slot(a) + (tow ? SC_TXT : SC_IMG);
             unsafeAtomicAdd(sc + 0, l1);
             unsafeAtomicAdd(sc + 1, 1.f - cosv);
             if (a.c.w_kl != 0.f) unsafeAtomicAdd(sc + 2, kl);
@@ -222,8 +232,9 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
     if (dir == 0) {
         pos = wave_sum(pos); neg = wave_sum(neg); mse = wave_sum(mse); diag = wave_sum(diag);
         if (lane == 0) {
-            unsafeAtomicAdd(a.scal + SC_POS, pos); unsafeAtomicAdd(a.scal + SC_NEG, neg);
-            unsafeAtomicAdd(a.scal + SC_MSE, mse); unsafeAtomicAdd(a.scal + SC_DIAG, diag);
+            float* sc = scal_slot(a);
+            unsafeAtomicAdd(sc + SC_POS, pos); unsafeAtomicAdd(sc + SC_NEG, neg);
+            unsafeAtomicAdd(sc + SC_MSE, mse); unsafeAtomicAdd(sc + SC_DIAG, diag);
         }
     }
     __syncthreads();
@@ -313,10 +324,10 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
     }
     if (a.c.w_sl != 0.f) {
         klacc = wave_sum(klacc);
-        if (lane == 0) unsafeAtomicAdd(a.scal + (dir ? SC_KL1 : SC_KL0), klacc);
+        if (lane == 0) unsafeAtomicAdd(scal_slot(a) + (dir ? SC_KL1 : SC_KL0), klacc);
     }
     if (a.c.w_hl != 0.f && z == 0 && wave == 0 && lane < 16 && i0 + lane < iend)
-        unsafeAtomicAdd(a.scal + (dir ? SC_LSE1 : SC_LSE0), __logf(grow ? grow[i0 + lane] : stat(rst, i0 - a.r0 + lane)) + 1.f);
+        unsafeAtomicAdd(scal_slot(a) + (dir ? SC_LSE1 : SC_LSE0), __logf(grow ? grow[i0 + lane] : stat(rst, i0 - a.r0 + lane)) + 1.f);
     __syncthreads();
     // gradient rows: G[16, E] = dS_stripe[16, B] @ Y[B, E],  Y = normalised student embedding of the other modality
     // (this slice's columns only: the slices' partial rows are added in loss_finalize_kernel)
@@ -389,6 +400,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
 
 // out[0] total ; [1..4] image l1,cos,kl,ce ; [5..8] text ; [9..12] cos_diff, hard_label, soft_label, logits_mse (raw)
 __global__ void loss_total_kernel(LossArgs a) {
+    __shared__ float tot[NSC];
+    if (threadIdx.x < NSC) {
+        float x = 0.f;
+        for (int r = 0; r < NREP; ++r) x += a.scal[r * SCSTRIDE + threadIdx.x];
+        tot[threadIdx.x] = x;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     const float B = (float)a.B, E = (float)a.E;
     const LossCfg& c = a.c;
@@ -397,14 +415,14 @@ __global__ void loss_total_kernel(LossArgs a) {
     const int ntow = c.two_tower ? 2 : 1;
     float total = 0.f;
     for (int t = 0; t < ntow; ++t) {
-        const float* sc = a.scal + (t ? SC_TXT : SC_IMG);
+        const float* sc = tot + (t ? SC_TXT : SC_IMG);
         float* ot = o + 1 + 4 * t;
         ot[0] = sc[0] / (B * E); ot[1] = sc[1] / B; ot[2] = sc[2] * c.tau * c.tau; ot[3] = sc[3] / B;
         const float tl = c.w_l1 * ot[0] + c.w_cos * ot[1] + c.w_kl * ot[2] + c.w_ce * ot[3];
         total += (c.two_tower ? 0.5f : 1.f) * tl;
     }
     if (c.two_tower) {
-        const float* s = a.scal;
+        const float* s = tot;
         // B = 1 with cos_diff switched on: mean over no negatives = 0 / 0 = NaN, as the reference (clip_cos_diff.py:16-23);
         // with the term off the raw value must stay finite (0 * NaN would poison the total)
         o[9] = s[SC_POS] / B + ((a.B > 1 || a.c.w_cd != 0.f) ? s[SC_NEG] / (B * (B - 1.f)) : 0.f);
@@ -424,7 +442,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t dclip_distill_loss_workspace(int64_t B, int64_t E) {
     const size_t be = align_up((size_t)B * E * sizeof(float));
     const size_t zs = 8;                                     // upper bound of loss_slices() for any row block
-    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up(NSC * 4);
+    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up((size_t)NREP * SCSTRIDE * 4);
 }
 
 namespace {
@@ -470,7 +488,7 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
     hipStream_t st = (hipStream_t)stream;
     // algorithmic HBM bytes: read 4*B*E*4 + write 2*rows*E*4 ; the logits contribute none
     TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 2.0 : 1.0) * (2.0 * (double)B + (double)rows) * E * 4.0, stream);
-    if (hipMemsetAsync(a.scal, 0, NSC * sizeof(float), st) != hipSuccess) {
+    if (hipMemsetAsync(a.scal, 0, (size_t)NREP * SCSTRIDE * sizeof(float), st) != hipSuccess) {
         dclip_set_error("%s: memset failed", who);
         return DCLIP_ELAUNCH;
     }
