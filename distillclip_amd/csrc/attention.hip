@@ -536,20 +536,41 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
     const int64_t hs = (int64_t)p.N * p.Np;
     const int rows = p.B * p.N;
     const int nchunk = p.Np >> 3, total = H * nchunk;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    // the next row's scores are fetched into registers BEFORE this row's P / R stores are issued: vmcnt retires loads and stores
+    // in one in-order queue, so loads that follow the stores could only be waited for together with the stores' acknowledgements
+    constexpr int NIT = (H * (COLS / 8) + 63) / 64;
+    float4 q0[NIT], q1[NIT];
+    auto fetch = [&](int row) {
+        const int64_t fb = ((int64_t)(row / p.N) * H * p.N + row % p.N) * p.Np;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + it * 64;
+            if (idx < total) {
+                const int h = idx / nchunk, ck = idx - h * nchunk;
+                const int64_t src = fb + h * hs + ck * 8;
+                q0[it] = *(const float4*)(p.S + src); q1[it] = *(const float4*)(p.S + src + 4);
+            }
+        }
+    };
+    const int row_first = blockIdx.x * 4 + wave, row_step = gridDim.x * 4;
+    if (row_first < rows) fetch(row_first);
+    for (int row = row_first; row < rows; row += row_step) {
         const int b = row / p.N, i = row % p.N;
         const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
         __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < total; idx += 64) {
-            const int h = idx / nchunk, ck = idx - h * nchunk;
-            const int64_t src = base + h * hs + ck * 8;
-            const float4 s0 = *(const float4*)(p.S + src), s1 = *(const float4*)(p.S + src + 4);
-            const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            bf16x8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { hi[e] = f2bf(v[e]); lo[e] = f2bf(v[e] - bf2f(hi[e])); }
-            *(bf16x8*)(tH + h * ROWB + ck * 16) = hi;
-            *(bf16x8*)(tL + h * ROWB + ck * 16) = lo;
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + it * 64;
+            if (idx < total) {
+                const int h = idx / nchunk, ck = idx - h * nchunk;
+                const float4 s0 = q0[it], s1 = q1[it];
+                const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { hi[e] = f2bf(v[e]); lo[e] = f2bf(v[e] - bf2f(hi[e])); }
+                *(bf16x8*)(tH + h * ROWB + ck * 16) = hi;
+                *(bf16x8*)(tL + h * ROWB + ck * 16) = lo;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -627,6 +648,7 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if (row + row_step < rows) fetch(row + row_step);
         for (int idx = lane; idx < total; idx += 64) {
             const int h = idx / nchunk, ck = idx - h * nchunk;
             const int64_t dst = base + h * hs + ck * 8;
