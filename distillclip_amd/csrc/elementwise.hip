@@ -208,6 +208,40 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
 }
 
+// float4 form of adamw_kernel (same per-element arithmetic).  The loads of the next grid-stride iteration are issued before the
+// stores of the current one: vmcnt retires loads and stores in one in-order queue, so loads that follow stores wait for the
+// stores' acknowledgements as well.
+__device__ __forceinline__ void adamw_elem(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps,
+                                           float wd, float bc1, float bc2_sqrt) {
+    pi = pi * (1.f - lr * wd);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+}
+__global__ __launch_bounds__(256) void adamw4_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                     float4* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2_sqrt, int zero_grad) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    for (;;) {
+        const int64_t nx = i + stride;
+        const bool more = nx < n4;
+        float4 pn = pi, gn = gi, mn = mi, vn = vi;
+        if (more) { pn = p[nx]; gn = g[nx]; mn = m[nx]; vn = v[nx]; }
+        adamw_elem(pi.x, gi.x, mi.x, vi.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.y, gi.y, mi.y, vi.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.z, gi.z, mi.z, vi.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.w, gi.w, mi.w, vi.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (!more) break;
+        i = nx; pi = pn; gi = gn; mi = mn; vi = vn;
+    }
+}
+
 // dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src into colsum (row length D)
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, bf16_t* __restrict__ dst_bf16,
                                                    int64_t n, float* __restrict__ colsum, int D) {
@@ -327,8 +361,17 @@ extern "C" int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, fl
     DCLIP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dclip_adamw: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2, zero_grad);
+    // 16-byte aligned buffers (the flat parameter layout guarantees it; odd slices fall back): float4 kernel for the multiple-of-4
+    // part, the scalar kernel for a tail of < 4 elements
+    int64_t n4 = 0;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) n4 = n / 4;
+    if (n4 > 0)
+        hipLaunchKernelGGL(adamw4_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
+                           (float4*)v, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, zero_grad);
+    const int64_t done = 4 * n4;
+    if (done < n)
+        hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n - done)), dim3(256), 0, (hipStream_t)stream, p + done, g + done, m + done,
+                           v + done, n - done, lr, beta1, beta2, eps, weight_decay, bc1, bc2, zero_grad);
     return dclip_check_launch("dclip_adamw");
 }
 
