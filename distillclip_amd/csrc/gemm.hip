@@ -1029,6 +1029,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     unsafeAtomicAdd(db + col, (s0 + s1) + (s2 + s3));
 }
 
+// 16-byte form: thread (cg = tid & 31, rl = tid >> 5) sums 8 consecutive columns over rows r0 + rl, r0 + rl + 8, ... ; the 8 row
+// lanes of a column group are combined through LDS, one atomic per column and block
+__global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__ X, int64_t ld, float* __restrict__ db,
+                                                      int M, int N, int rows_per_block) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col < N) {
+        int r = r0 + rl;
+        for (; r + 24 < r1; r += 32) {                       // four rows in flight per thread
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(X + (int64_t)(r + 8 * u) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[u][e]);
+        }
+        for (; r < r1; r += 8) {
+            const bf16x8 v = *(const bf16x8*)(X + (int64_t)r * ld + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) x += red[w][threadIdx.x];
+        unsafeAtomicAdd(db + c, x);
+    }
+}
+
 bool use_256(const GemmNT& p) {
     static const int mode = [] { const char* e = getenv("DCLIP_GEMM256"); return e ? atoi(e) : 2; }();
     if (mode == 0 || p.M < 1024 || p.N < 256) return false;
@@ -1227,7 +1268,11 @@ extern "C" int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M,
     int rows_per_block = (int)((M * colblocks + 511) / 512);
     rows_per_block = rows_per_block < 16 ? 16 : (rows_per_block > 512 ? 512 : (rows_per_block + 3) & ~3);
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ld, db, (int)M, (int)N,
-                       rows_per_block);
+    if (N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)X & 15) == 0)
+        hipLaunchKernelGGL(colsum8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ld, db, (int)M, (int)N,
+                           rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ld, db, (int)M, (int)N,
+                           rows_per_block);
     return dclip_check_launch("dclip_colsum_acc");
 }

@@ -138,6 +138,13 @@ def test_colsum():
     db = torch.zeros(300, device='cuda')
     ops.colsum_acc(x, db)
     _close(db, x.float().sum(0), 1e-5)
+    # 16-byte path (N % 8 == 0): ragged rows, a column slice of a wider buffer (ld > N), the qkv-bias shape of the step
+    for M, N, full in ((1037, 304, 304), (4099, 768, 2304), (51200, 2304, 2304)):
+        xf = _rand((M, full), 14)
+        xs = xf[:, full - N:]
+        db = torch.ones(N, device='cuda')
+        ops.colsum_acc(xs, db)
+        _close(db, 1.0 + xs.float().sum(0), 2e-5 * max(1.0, (M / 1000) ** 0.5))
 
 
 @pytest.mark.parametrize('M,N,K', [(1024, 256, 64), (1024, 256, 128), (1100, 264, 192), (2048, 768, 768), (1500, 512, 256),
