@@ -235,50 +235,96 @@ def cpu_baseline(wl, seed, budget_s=40.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher: N fresh rank processes, started before this process makes any GPU call
 # ---------------------------------------------------------------------------------------------------------------------
-def launch_ranks(n, argv):
-    import socket
+def launch_ranks(n, argv, timeout_s=1800.0, grace_s=120.0):
+    """Start n fresh rank processes (before this process makes any GPU call) and wait for them.
+
+    Rendezvous is a torch.distributed FileStore in a private temporary directory (DCLIP_RDZV_FILE): there is no port to pick, so
+    no bind-then-close race.  Deadlines: every rank must finish within timeout_s, and once the first rank has exited the others get
+    grace_s to follow (a rank stuck in a collective would otherwise block the launcher until an outside kill).  On any failure the
+    remaining children are terminated (then killed) and the exit code is non-zero.  Children are always NEW processes: a process
+    that has touched the GPU is never re-executed."""
+    import shutil
     import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    import tempfile
+    rdzv_dir = tempfile.mkdtemp(prefix='dclip_rdzv_')
+    rdzv = os.path.join(rdzv_dir, 'store')
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), DCLIP_RDZV_FILE=rdzv)
+        env.pop('MASTER_PORT', None)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # rank 0 inherits stdout (its JSON line is this command's output); the other ranks' stdout goes to stderr
         out = None if r == 0 else sys.stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
     rc = 0
     alive = list(procs)
+    t_start = time.monotonic()
+    t_first_exit = None
+    why = None
     while alive:
-        time.sleep(0.2)
+        time.sleep(0.1)
         for p in list(alive):
             code = p.poll()
             if code is None:
                 continue
             alive.remove(p)
+            if t_first_exit is None:
+                t_first_exit = time.monotonic()
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
-                for q in alive:                 # a rank failed: the others would wait in a collective forever
-                    q.terminate()
+                why = f'rank {procs.index(p)} exited with code {code}'
+        now = time.monotonic()
+        if rc == 0 and alive and now - t_start > timeout_s:
+            rc, why = 124, f'{len(alive)} rank(s) still running after the {timeout_s:.0f} s deadline'
+        if rc == 0 and alive and t_first_exit is not None and now - t_first_exit > grace_s:
+            rc, why = 124, f'{len(alive)} rank(s) still running {grace_s:.0f} s after the first rank exited'
+        if rc != 0 and alive:
+            # a rank failed or hung: the others would wait in a collective forever
+            print(f'bench.py launcher: {why}; terminating {len(alive)} remaining rank(s)', file=sys.stderr, flush=True)
+            for q in alive:
+                q.terminate()
+            t_kill = time.monotonic() + 10.0
+            while any(q.poll() is None for q in alive) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            for q in alive:
+                if q.poll() is None:
+                    q.kill()
+            for q in alive:
+                q.wait()
+            alive = []
     if rc == 0 and any(p.returncode != 0 for p in procs):
         rc = 1
+    shutil.rmtree(rdzv_dir, ignore_errors=True)
     return rc
 
 
-def dry_launch():
-    """launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 reports the world size the ranks observed"""
-    import torch
+def init_dist(backend, rank, world, device=None):
+    """Join the process group: FileStore named by the launcher (DCLIP_RDZV_FILE), else env:// (torch.distributed.run)."""
     import torch.distributed as dist
+    kw = {'device_id': device} if device is not None else {}
+    rdzv = os.environ.get('DCLIP_RDZV_FILE')
+    if rdzv:
+        dist.init_process_group(backend, init_method='file://' + rdzv, rank=rank, world_size=world, **kw)
+    else:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def dry_launch():
+    """launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 reports the world size the ranks observed.
+    DCLIP_DRY_HANG_RANK=r (or 'all') makes rank r sleep forever after the collective (launcher deadline test)."""
+    import torch
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist = init_dist('gloo', rank, world)
     t = torch.ones(1)
     dist.all_reduce(t)
     if rank == 0:
-        print(json.dumps({'dry_launch': True, 'n_gpus': int(t.item()), 'backend': 'gloo'}), flush=True)
+        print(json.dumps({'dry_launch': True, 'n_gpus': dist.get_world_size(), 'ranks_seen': int(t.item()), 'backend': 'gloo'}), flush=True)
     dist.barrier()
+    if os.environ.get('DCLIP_DRY_HANG_RANK') in (str(rank), 'all'):
+        time.sleep(3600)
     dist.destroy_process_group()
 
 
@@ -293,6 +339,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dry-launch', action='store_true', help='spawn the ranks, join a gloo group on the CPU, exit (launcher test)')
+    ap.add_argument('--launch-timeout', type=float, default=1800.0, help='launcher: seconds every rank has to finish')
+    ap.add_argument('--launch-grace', type=float, default=120.0, help='launcher: seconds the other ranks get after the first one exited')
     ap.add_argument('--global-negatives', action='store_true',
                     help='opt-in north-star mode: in-batch negatives over all ranks (all-gather of the embeddings over RCCL)')
     ap.add_argument('--teacher-text-prefix', action='store_true',
@@ -301,7 +349,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # nothing above touched the GPU (torch is not even imported)
+        # nothing above touched the GPU (torch is not even imported)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout, args.launch_grace))
     if args.dry_launch:
         return dry_launch()
 
@@ -322,12 +371,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     use_dist = world > 1 or os.environ.get('DCLIP_FORCE_DIST') == '1'      # the latter: exercise the RCCL path on one GPU
+    ranks_seen = 1
     if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        dist = init_dist('nccl', rank, world, device)
         world = dist.get_world_size()                       # n_gpus reported = the RCCL world size the ranks observed
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                               # census on the device: every rank really took part in an RCCL collective
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f'RCCL census: all-reduce of ones gave {ranks_seen}, world size {world}')
 
     from distillclip_amd._lib import lib
     wl = WORKLOADS[args.config]
@@ -465,7 +517,7 @@ def main():
             dp = 'reduce-scatter -> sharded AdamW -> all-gather' if getattr(model._sync, 'sharded', False) else 'all-reduce'
         out = {
             'metric': wl['metric'], 'value': round(value, 2), 'unit': f'{wl["unit"]}/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'n_gpus': world, 'rccl_ranks_seen': ranks_seen if use_dist else None, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': wl['desc'], 'name': args.config,
                        'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}', 'gradient_exchange': dp,

@@ -1,0 +1,646 @@
+// Head-mixed student attention, score stage, with BOTH head mixes on the matrix pipe and no lane movement.
+//
+//   reference: model/component/weight_share_model.py:101-125 (MiniAttention.forward)
+//       S_h = scale * Q_h K_h^T ; A = conv_l(S) (1x1 conv over the head channel) ; P = softmax_j(A) ; R = conv_w(P)
+//
+// This header is the per-WAVE algorithm.  It is compiled twice: by hipcc for gfx950 (attention_mix.hip) and by the host compiler
+// against a 64-lane emulation of the wave collectives (tools/emu/) that checks the lane / register index maps on the CPU.
+//
+// One wave owns (sample b, 16 query rows); lane = (c, g4) = (lane & 15, lane >> 4), c <-> query i0 + c.  Keys are walked four
+// at a time ("quad" j0 .. j0 + 3).  v_mfma_f32_16x16x32 computes D[row][col] += sum_k A[row][k] B[k][col] with
+//   A fragment of lane l = A[row = l & 15][k = 8 (l >> 4) + 0..7],  B fragment = B[k = 8 (l >> 4) + 0..7][col = l & 15],
+//   accumulator register r of lane l = D[row = 4 (l >> 4) + r][col = l & 15].
+//
+// (1) BLOCK-DIAGONAL scores.  For a set s of four heads, rows of the MFMA are (head-in-set hh, key-in-quad jk) = 4 hh + jk and the
+//     k slots are (lane group grp, 8 channels): A[(hh, jk)][(grp, d8)] = [grp == hh] K_{4s+hh}[j0 + jk][8 ci + d8],
+//     B[(grp, d8)][c] = Q_{4s+grp}[i0 + c][8 ci + d8].  Summed over the HD / 8 channel chunks ci, accumulator register r of lane
+//     (c, g4) is S_{4s+g4}[i0 + c][j0 + r]: lane group g4 ends up with head 4s + g4.  Three quarters of the A operand are zeros
+//     (the 16 lanes with (c >> 2) == g4 carry a key row each) -- four times the MFMA work of a dense tile, on a pipe that is idle.
+// (2) MIX 1 from that layout.  For key j0 + r, the packed values {S-acc[s][r] : s} of lane (c, g4) ARE a B fragment whose k slot
+//     (g4, jj) means head 4 jj + g4; with the mix matrix as the A operand (columns permuted the same way) one MFMA per 16 output
+//     heads gives A[g][c] for that key: accumulator register r' of lane (c, g4) <-> output head 16 t + 4 g4 + r'.
+// (3) Softmax statistics are per (output head, query) = per accumulator register of a lane: running maximum / sum over the keys are
+//     plain register updates, no cross-lane step at all.  -lse enters as the initial accumulator, so P = exp2(mfma result).
+// (4) MIX 2 (and the adjoint mixes of the backward) contract over the ROW index of an accumulator tile, so the packed accumulator
+//     registers are the next B fragment as they stand (k slot (g4, jj) <-> head 16 (jj >> 2) + 4 g4 + (jj & 3)).
+//
+// Precision: q, k, v, dO are bf16 (exact products, f32 accumulation).  The forward mixes run on f16 operands (11-bit mantissa:
+// the precision the reference's fp16 autocast gives conv_l / conv_w); the backward's gradient-side operands are bf16 (range).
+#pragma once
+#include <type_traits>
+
+namespace amix {
+
+template <int H_, int HD_>
+struct Cfg {
+    static constexpr int H = H_, HD = HD_;
+    static constexpr int D = H * HD;
+    static constexpr int NS = (H + 3) / 4;       // sets of four heads
+    static constexpr int RT = (H + 15) / 16;     // 16-row tiles of a mixed tensor
+    static constexpr int NC = HD / 8;            // 8-channel chunks of a head row
+    static constexpr int HP = 16 * RT;           // padded head count of the weight-gradient tiles
+};
+
+template <class T8> struct elem_of;
+template <> struct elem_of<bf16x8> { typedef bf16_t type; };
+template <> struct elem_of<f16x8> { typedef _Float16 type; };
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 24.f;              // lazy rescale of the running softmax reference (log2 units)
+constexpr float P_OFF = 1e30f;                   // "log-sum-exp" of rows that must come out as P = 0
+
+struct FwdArgs {
+    const bf16_t* qkv; long ld;                  // [B*N, 3D]: q | k | v, head h at column h * HD
+    const float* Wl; const float* Ww;            // [H, H] conv_l / conv_w weights (f32 masters)
+    bf16_t* R;                                   // [B, H, N, Np] mixed probabilities, pad columns zero
+    float* stats;                                // [B, H, N] log-sum-exp (natural log) of row (b, h, i) of A
+    int B, N, Np, QT;
+    float scale;
+};
+
+struct BwdArgs {
+    const bf16_t* qkv; long ld;
+    const bf16_t* dO; long ldo;                  // [B*N, D] gradient of ctx
+    const float* Wl; const float* Ww;
+    const float* stats;
+    bf16_t* dS;                                  // [B, H, N, Np] gradient of the scaled pre-mix scores, pad columns zero
+    float* partial;                              // [workgroups][2][HP][HP] weight-gradient partial sums (dW_l, dW_w)
+    int B, N, Np, QT;
+    float scale;
+};
+
+// ---- weight operands -------------------------------------------------------------------------------------------------------
+// A fragment of an [H, H] mix matrix for the products above.  elem(out, in) returns M[out][in].
+//   SLAYOUT: k slot (grp, jj) <-> input head 4 jj + grp            (B operand packed from block-diagonal score accumulators)
+//   else   : k slot (grp, jj) <-> input head 16 (jj >> 2) + 4 grp + (jj & 3)   (B operand packed from a mixed accumulator tile)
+template <class C, bool SLAYOUT, class T8, class F>
+DEVFN T8 weight_frag(int lane, int t, F elem) {
+    const int row = 16 * t + (lane & 15), grp = lane >> 4;
+    T8 f;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int in = SLAYOUT ? 4 * jj + grp : 16 * (jj >> 2) + 4 * grp + (jj & 3);
+        const bool ok = row < C::H && in < C::H && (!SLAYOUT || jj < C::NS);
+        f[jj] = (typename elem_of<T8>::type)(ok ? elem(row, in) : 0.f);
+    }
+    return f;
+}
+
+// ---- block-diagonal scores ---------------------------------------------------------------------------------------------------
+// Column-entity fragments (queries here): lane (c, g4) holds rows of head 4s + g4 of token `tok`, chunk ci.
+template <class C>
+DEVFN void load_col_frags(const bf16_t* mat, long ld, int tok, bool tok_ok, int lane, bf16x8 (&f)[C::NS][C::NC]) {
+    const int g4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        const bool ok = tok_ok && 4 * s + g4 < C::H;
+        const bf16_t* src = mat + (long)tok * ld + (4 * s + g4) * C::HD;
+#pragma unroll
+        for (int ci = 0; ci < C::NC; ++ci) {
+            bf16x8 z = {};
+            f[s][ci] = ok ? *(const bf16x8*)(src + 8 * ci) : z;
+        }
+    }
+}
+
+// ---- row matrices (keys, values) through a wave-private LDS ring ----------------------------------------------------------------
+// A quad of token rows (4 x D bf16) is one stage, filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging) one quad
+// ahead of its use.  LDS-DMA writes lane-linear, so the layout is chosen on the SOURCE side: position (row r, chunk cp) of a stage
+// holds source chunk cp ^ r of row r0 + r, which puts the 4 rows of one head chunk on 4 different bank groups for the
+// ds_read_b128 fragment reads below.  Rows >= nrows are read from a zero page.
+template <class C>
+struct Ring {
+    static constexpr int ROWB = C::D * 2;            // bytes of one token row (all heads)
+    static constexpr int STAGE = 4 * ROWB;           // one quad
+    static constexpr int NINST = STAGE / 1024;       // LDS-DMA wave-instructions per stage (D % 128 == 0)
+    static constexpr int CPR = C::D / 8;             // 16-byte chunks per row
+};
+
+template <class C>
+DEVFN void stage_quad(const bf16_t* rows, long ld, int r0, int nrows, const bf16_t* zero_page, char* stage, int lane) {
+    constexpr int CPR = Ring<C>::CPR;
+#pragma unroll
+    for (int k = 0; k < Ring<C>::NINST; ++k) {
+        const int pos = k * 64 + lane;
+        const int r = pos / CPR, cp = pos - r * CPR;
+        const int row = r0 + r;
+        const bf16_t* src = (row < nrows ? rows + (long)row * ld : zero_page) + ((cp ^ r) << 3);
+        hw::dma16(src, stage + k * 1024);
+    }
+}
+
+// acc[s][r] (lane (c, g4)) = sum_d Row_{4s+g4}[r0 + r][d] * Col_{4s+g4}[c][d], rows from a staged quad.  The 16 lanes with
+// (c >> 2) == g4 carry one row each (head-in-set g4, key-in-quad c & 3); the other 48 read the wave's zero block.
+template <class C>
+DEVFN void bd_scores(const char* stage, const char* zeros, int lane, const bf16x8 (&colf)[C::NS][C::NC], f32x4 (&acc)[C::NS]) {
+    constexpr int NS = C::NS, NC = C::NC;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int row = c & 3;
+    const bool lane_ok = (c >> 2) == g4;
+    const char* base = lane_ok ? stage + row * Ring<C>::ROWB + 16 * g4 * NC : zeros;
+    const int x = lane_ok ? row : 0;
+    // fragment reads run AHEAD sets ahead of the MFMA chain that consumes them (one wave per SIMD: nothing else hides LDS latency)
+    constexpr int AHEAD = NS < 3 ? NS : 3;
+    bf16x8 kf[NS][NC];
+    auto fetch = [&](int s) {
+        const bool head_ok = (C::H % 4 == 0) || 4 * s + g4 < C::H;
+        const char* ps = head_ok ? base : zeros;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) kf[s][ci] = *(const bf16x8*)(ps + 16 * (4 * s * NC + (ci ^ x)));
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) fetch(s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + AHEAD < NS) fetch(s + AHEAD);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) a = hw::mfma_bf16(kf[s][ci], colf[s][ci], a);
+        acc[s] = a;
+    }
+}
+
+// NMAT row matrices walked quad by quad through a double-buffered ring: stage (2 m + parity) belongs to matrix m.
+template <class C, int NMAT>
+struct RowStream {
+    const bf16_t* rows[NMAT];
+    long ld; int nrows;
+    const bf16_t* zero_page;
+    char* ring;
+    int lane, par;
+    DEVMEM void issue(int q, int pp) const {
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) stage_quad<C>(rows[m], ld, 4 * q, nrows, zero_page, ring + (2 * m + pp) * Ring<C>::STAGE, lane);
+    }
+    // quad `next` is requested into the other parity, then everything older than that request has landed: the current quad
+    DEVMEM void advance(int next) {
+        issue(next, par ^ 1);
+        hw::dma_wait<NMAT * Ring<C>::NINST>();
+    }
+    DEVMEM const char* stage(int m) const { return ring + (2 * m + par) * Ring<C>::STAGE; }
+    DEVMEM void done() { par ^= 1; }
+};
+
+// B fragment of the first-kind mix for instance r of the quad: k slot (g4, jj) <- acc[jj][r]
+template <class C, class T8>
+DEVFN T8 pack_s(const f32x4 (&acc)[C::NS], int r) {
+    T8 f = {};
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) f[s] = (typename elem_of<T8>::type)acc[s][r];
+    return f;
+}
+// B fragment of the second-kind mix: k slot (g4, jj) <- x[jj >> 2][jj & 3]
+template <class C, class T8>
+DEVFN T8 pack_a(const f32x4 (&x)[C::RT]) {
+    T8 f = {};
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[4 * t + k] = (typename elem_of<T8>::type)x[t][k];
+    return f;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+template <class C>
+struct FwdWeights {
+    f16x8 wl[C::RT];     // log2(e) * scale * W_l, first-kind layout
+    f16x8 ww[C::RT];     // W_w, second-kind layout
+};
+
+template <class C>
+DEVFN void fwd_load_weights(const FwdArgs& p, int lane, FwdWeights<C>& w) {
+    const float* Wl = p.Wl; const float* Ww = p.Ww;
+    const float sc = p.scale * LOG2E;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t) {
+        w.wl[t] = weight_frag<C, true, f16x8>(lane, t, [&](int g, int h) { return Wl[g * C::H + h] * sc; });
+        w.ww[t] = weight_frag<C, false, f16x8>(lane, t, [&](int g, int h) { return Ww[g * C::H + h]; });
+    }
+}
+
+template <class C>
+constexpr int fwd_lds_per_wave() { return Ring<C>::ROWB + 2 * Ring<C>::STAGE; }        // zero block + the key ring
+
+// One (sample, 16-query tile): pass 1 = softmax statistics, pass 2 = P, R.  R is written as 16-byte groups of 8 keys.
+// lds: this wave's region (fwd_lds_per_wave bytes), its first ROWB bytes already zero.
+template <class C>
+DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<C>& w, char* lds, const bf16_t* zero_page) {
+    constexpr int NS = C::NS, RT = C::RT, H = C::H, D = C::D;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int N = p.N;
+    const int i = it * 16 + c;
+    const bool iok = i < N;
+    const bf16_t* base = p.qkv + (long)b * N * p.ld;
+    bf16x8 qf[NS][C::NC];
+    load_col_frags<C>(base, p.ld, i, iok, lane, qf);
+    const char* zeros = lds;
+    RowStream<C, 1> ks{{base + D}, p.ld, N, zero_page, lds + Ring<C>::ROWB, lane, 0};
+    const int nq = (N + 3) >> 2;
+
+    // ---- pass 1: reference value from the first quad, then running sums with a lazy rescale ------------------------------------
+    f32x4 m[RT], l[RT];
+    ks.issue(0, 0);
+    hw::dma_wait<0>();
+    {
+        f32x4 sa[NS];
+        bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < N) {
+                const f16x8 pk = pack_s<C, f16x8>(sa, r);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 a = hw::mfma_f16(w.wl[t], pk, z);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[t][k] = r == 0 ? a[k] : fmaxf(m[t][k], a[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) l[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // TAIL (compile time) = the quad may reach past N: only that variant carries the per-key validity branches
+    auto stats_quad = [&](auto tail_c, int q) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        ks.advance(q + 1 < nq ? q + 1 : 0);          // the last request is quad 0 of pass 2
+        f32x4 sa[NS];
+        bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
+        ks.done();
+        // the quad's scores minus the reference first, the decision to move the reference next, the exponentials last: nothing
+        // is ever exponentiated against a reference it exceeds by more than RESCALE_THR
+        f32x4 av[4][RT], mx[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) mx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!TAIL || 4 * q + r < N) {
+                const f16x8 pk = pack_s<C, f16x8>(sa, r);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    av[r][t] = hw::mfma_f16(w.wl[t], pk, -m[t]);               // log2-domain score minus the reference
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mx[t][k] = fmaxf(mx[t][k], av[r][t][k]);
+                }
+            }
+        }
+        bool big = false;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) big = big || mx[t][k] > RESCALE_THR;
+        if (hw::any(big)) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = mx[t][k];
+                    m[t][k] += d;
+                    l[t][k] *= hw::exp2(-d);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[r][t][k] -= d;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!TAIL || 4 * q + r < N) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) l[t][k] += hw::exp2(av[r][t][k]);
+            }
+        }
+    };
+    const int nqf = N >> 2;                          // quads that lie entirely below N
+    for (int q = 0; q < nqf; ++q) stats_quad(std::false_type{}, q);
+    if (nqf < nq) stats_quad(std::true_type{}, nqf);
+    f32x4 nlse[RT];                                  // minus the log2-domain log-sum-exp: initial accumulator of pass 2
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = 16 * t + 4 * g4 + k;
+            const float lse2 = m[t][k] + hw::log2(l[t][k]);
+            nlse[t][k] = -lse2;
+            if (iok && g < H) p.stats[((long)b * H + g) * N + i] = lse2 * LN2;
+        }
+
+    // ---- pass 2: P = exp2(A' - lse'), R = conv_w(P), 8 keys per 16-byte store ------------------------------------------------------
+    const int nblk = p.Np >> 3;
+    auto block = [&](auto tail_c, int kb) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        bf16x8 rp[RT][4];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rp[t][k] = bf16x8{};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int u = 2 * kb + hf, j0 = 4 * u;
+            if (!TAIL || u < nq) {
+                if (u + 1 < nq) ks.advance(u + 1); else hw::dma_wait<0>();
+                f32x4 sa[NS];
+                bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
+                ks.done();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!TAIL || j0 + r < N) {
+                        const f16x8 pk = pack_s<C, f16x8>(sa, r);
+                        f32x4 pr[RT];
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const f32x4 a = hw::mfma_f16(w.wl[t], pk, nlse[t]);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) pr[t][k] = hw::exp2(a[k]);
+                        }
+                        const f16x8 pp = pack_a<C, f16x8>(pr);
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 rr = hw::mfma_f16(w.ww[t], pp, z);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) rp[t][k][4 * hf + r] = (bf16_t)rr[k];
+                        }
+                    }
+                }
+            }
+        }
+        if (iok) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int g = 16 * t + 4 * g4 + k;
+                    if (g < H) *(bf16x8*)(p.R + (((long)b * H + g) * N + i) * p.Np + 8 * kb) = rp[t][k];
+                }
+        }
+    };
+    const int nbf = N >> 3;                          // 8-key blocks that lie entirely below N
+    for (int kb = 0; kb < nbf; ++kb) block(std::false_type{}, kb);
+    if (nbf < nblk) block(std::true_type{}, nbf);
+}
+
+// the wave's zero block (read by the 48 lanes of a block-diagonal A operand that carry no row)
+template <class C>
+DEVFN void zero_block_init(char* lds, int lane) {
+    for (int o = lane * 16; o < Ring<C>::ROWB; o += 64 * 16) *(u32x4*)(lds + o) = u32x4{0u, 0u, 0u, 0u};
+    hw::lds_fence();
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------------
+// weight-gradient products go through a wave-private LDS tile per operand: [32 head rows][64 elements] bf16, rows padded to 144 B
+constexpr int WG_ROWB = 144;
+constexpr int WG_TILE = 32 * WG_ROWB;            // 4608 B
+template <class C>
+constexpr int bwd_tile_off() { return Ring<C>::ROWB + 4 * Ring<C>::STAGE; }              // zero block, key ring, value ring
+template <class C>
+constexpr int bwd_lds_per_wave() { return bwd_tile_off<C>() + 2 * WG_TILE; }              // ... + the two tiles (9216 B >= 2 * 32 * 32 * 4)
+
+template <class C>
+struct BwdWeights {
+    f16x8 wl[C::RT];      // forward mix 1 (as the forward: log2(e) * scale * W_l)
+    bf16x8 wwt[C::RT];    // dP_h = sum_g W_w[g, h] dR_g   : out = h, in = g, first-kind layout (dR comes from block-diagonal products)
+    bf16x8 wlt[C::RT];    // dS_h = sum_g W_l[g, h] dA_g   : out = h, in = g, second-kind layout
+};
+
+template <class C>
+DEVFN void bwd_load_weights(const BwdArgs& p, int lane, BwdWeights<C>& w) {
+    const float* Wl = p.Wl; const float* Ww = p.Ww;
+    const float sc = p.scale * LOG2E;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t) {
+        w.wl[t] = weight_frag<C, true, f16x8>(lane, t, [&](int g, int h) { return Wl[g * C::H + h] * sc; });
+        w.wwt[t] = weight_frag<C, true, bf16x8>(lane, t, [&](int h, int g) { return Ww[g * C::H + h]; });
+        w.wlt[t] = weight_frag<C, false, bf16x8>(lane, t, [&](int h, int g) { return Wl[g * C::H + h]; });
+    }
+}
+
+// tile rows of a first-kind tensor (value v[s][r]: head 4s + g4, element (c, r)) / second-kind tensor (x[r][t][k]: head 16t + 4g4 + k)
+template <class C>
+DEVFN void wg_store_s(char* tile, int lane, const f32x4 (&v)[C::NS], float mul) {
+    const int c = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        const bf16x4 o = {(bf16_t)(v[s][0] * mul), (bf16_t)(v[s][1] * mul), (bf16_t)(v[s][2] * mul), (bf16_t)(v[s][3] * mul)};
+        *(bf16x4*)(tile + (4 * s + g4) * WG_ROWB + c * 8) = o;
+    }
+}
+template <class C>
+DEVFN void wg_store_a(char* tile, int lane, const f32x4 (&x)[4][C::RT]) {
+    const int c = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < C::RT; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf16x4 o = {(bf16_t)x[0][t][k], (bf16_t)x[1][t][k], (bf16_t)x[2][t][k], (bf16_t)x[3][t][k]};
+            *(bf16x4*)(tile + (16 * t + 4 * g4 + k) * WG_ROWB + c * 8) = o;
+        }
+}
+// acc[t][u] (rows g = 16t + .., columns h = 16u + ..) += sum over the 64 elements of X[g][e] Y[h][e]
+template <class C>
+DEVFN void wg_product(const char* tx, const char* ty, int lane, f32x4 (&acc)[C::RT][C::RT]) {
+    const int c = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xa[C::RT], yb[C::RT];
+#pragma unroll
+        for (int t = 0; t < C::RT; ++t) {
+            xa[t] = *(const bf16x8*)(tx + (16 * t + c) * WG_ROWB + (32 * ks + 8 * g4) * 2);
+            yb[t] = *(const bf16x8*)(ty + (16 * t + c) * WG_ROWB + (32 * ks + 8 * g4) * 2);
+        }
+#pragma unroll
+        for (int t = 0; t < C::RT; ++t)
+#pragma unroll
+            for (int u = 0; u < C::RT; ++u) acc[t][u] = hw::mfma_bf16(xa[t], yb[u], acc[t][u]);
+    }
+}
+
+template <class C>
+struct BwdAcc {
+    f32x4 ww[C::RT][C::RT];     // dW_w[g, h] += sum dR_g P_h
+    f32x4 wl[C::RT][C::RT];     // dW_l[g, h] += sum dA_g S_h
+};
+
+// One (sample, 16-query tile).  pass A: delta_h = sum_j P_h dP_h (and dW_w); pass B: dA, dS (and dW_l).
+template <class C>
+DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<C>& w, BwdAcc<C>& acc, char* lds,
+                    const bf16_t* zero_page) {
+    constexpr int NS = C::NS, RT = C::RT, H = C::H, D = C::D;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int N = p.N;
+    const int i = it * 16 + c;
+    const bool iok = i < N;
+    char* tx = lds + bwd_tile_off<C>();
+    char* ty = tx + WG_TILE;
+    const char* zeros = lds;
+    const bf16_t* base = p.qkv + (long)b * N * p.ld;
+    bf16x8 qf[NS][C::NC], dof[NS][C::NC];
+    load_col_frags<C>(base, p.ld, i, iok, lane, qf);
+    load_col_frags<C>(p.dO + (long)b * N * p.ldo, p.ldo, i, iok, lane, dof);
+    RowStream<C, 2> kv{{base + D, base + 2 * D}, p.ld, N, zero_page, lds + Ring<C>::ROWB, lane, 0};
+    f32x4 nlse[RT], delta[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = 16 * t + 4 * g4 + k;
+            // padded heads and queries beyond N: P = 0, so they drop out of every sum below
+            nlse[t][k] = (iok && g < H) ? -p.stats[((long)b * H + g) * N + i] * LOG2E : -P_OFF;
+            delta[t][k] = 0.f;
+        }
+    const int nq = (N + 3) >> 2;
+
+    // S, dR of a quad; P, dP per key of the quad
+    // quads 0 .. nq - 1 twice (pass A, pass B), each requested one quad ahead
+    kv.issue(0, 0);
+    int seq = 0;
+    auto quad = [&](auto tail_c, int j0, f32x4 (&sa)[NS], f32x4 (&dra)[NS], f32x4 (&pr)[4][RT], f32x4 (&dp)[4][RT]) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        ++seq;
+        if (seq < 2 * nq) kv.advance(seq < nq ? seq : seq - nq); else hw::dma_wait<0>();
+        bd_scores<C>(kv.stage(0), zeros, lane, qf, sa);
+        bd_scores<C>(kv.stage(1), zeros, lane, dof, dra);
+        kv.done();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!TAIL || j0 + r < N) {
+                const f16x8 pk = pack_s<C, f16x8>(sa, r);
+                const bf16x8 dk = pack_s<C, bf16x8>(dra, r);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const f32x4 a = hw::mfma_f16(w.wl[t], pk, nlse[t]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pr[r][t][k] = hw::exp2(a[k]);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) { pr[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        }
+    };
+
+    // ---- pass A ---------------------------------------------------------------------------------------------------------------
+    auto pass_a = [&](auto tail_c, int q) {
+        f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
+        quad(tail_c, 4 * q, sa, dra, pr, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) delta[t][k] += pr[r][t][k] * dp[r][t][k];
+        // dW_w[g, h] += sum_e dR_g[e] P_h[e]
+        hw::lds_fence();
+        wg_store_s<C>(tx, lane, dra, 1.f);
+        wg_store_a<C>(ty, lane, pr);
+        hw::lds_fence();
+        wg_product<C>(tx, ty, lane, acc.ww);
+    };
+    const int nqf = N >> 2;
+    for (int q = 0; q < nqf; ++q) pass_a(std::false_type{}, q);
+    if (nqf < nq) pass_a(std::true_type{}, nqf);
+
+    // ---- pass B ---------------------------------------------------------------------------------------------------------------
+    const int nblk = p.Np >> 3;
+    auto pass_b = [&](auto tail_c, int kb) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        bf16x8 sp[RT][4];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x8{};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int j0 = 8 * kb + 4 * hf;
+            if (!TAIL || 2 * kb + hf < nq) {
+                f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
+                quad(tail_c, j0, sa, dra, pr, dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA
+                    if (!TAIL || j0 + r < N) {
+                        const bf16x8 da = pack_a<C, bf16x8>(dp[r]);
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 ds = hw::mfma_bf16(w.wlt[t], da, z);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sp[t][k][4 * hf + r] = (bf16_t)ds[k];
+                        }
+                    }
+                }
+                // dW_l[g, h] += sum_e dA_g[e] S_h[e]   (S = scale * raw scores)
+                hw::lds_fence();
+                wg_store_a<C>(tx, lane, dp);
+                wg_store_s<C>(ty, lane, sa, p.scale);
+                hw::lds_fence();
+                wg_product<C>(tx, ty, lane, acc.wl);
+            }
+        }
+        if (iok) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int g = 16 * t + 4 * g4 + k;
+                    if (g < H) *(bf16x8*)(p.dS + (((long)b * H + g) * N + i) * p.Np + 8 * kb) = sp[t][k];
+                }
+        }
+    };
+    const int nbf = N >> 3;
+    for (int kb = 0; kb < nbf; ++kb) pass_b(std::false_type{}, kb);
+    if (nbf < nblk) pass_b(std::true_type{}, nbf);
+}
+
+// Persistent wave: items wave0, wave0 + nwaves, ...; at the end the workgroup's waves add their weight-gradient tiles through
+// LDS and the workgroup writes ONE partial [2][HP][HP] (summed by a second, tiny launch: no same-line atomics).
+template <class C>
+DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int lane, char* lds_all, const bf16_t* zero_page) {
+    constexpr int RT = C::RT, HP = C::HP;
+    constexpr int PER_WAVE = bwd_lds_per_wave<C>(), TILE_OFF = bwd_tile_off<C>();
+    char* lds = lds_all + wave * PER_WAVE;
+    // the zero block; rows of the tiles that no product writes stay finite
+    for (int o = lane * 16; o < 2 * WG_TILE; o += 64 * 16) *(u32x4*)(lds + TILE_OFF + o) = u32x4{0u, 0u, 0u, 0u};
+    zero_block_init<C>(lds, lane);
+    BwdWeights<C> w;
+    bwd_load_weights<C>(p, lane, w);
+    BwdAcc<C> acc;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < RT; ++u) { acc.ww[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.wl[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int nitem = p.B * p.QT;
+    for (int item = wg * nwave + wave; item < nitem; item += nwg * nwave) {
+        const int b = item / p.QT, it = item - b * p.QT;
+        bwd_item<C>(p, b, it, lane, w, acc, lds, zero_page);
+    }
+    // accumulator layout: row g = 16t + 4 g4 + r, column h = 16u + c
+    hw::lds_fence();
+    float* mine = (float*)(lds + TILE_OFF);          // [2][HP][HP] f32 = 8 KiB at HP = 32
+    const int c = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = 16 * t + 4 * g4 + r, h = 16 * u + c;
+                mine[g * HP + h] = acc.wl[t][u][r];
+                mine[HP * HP + g * HP + h] = acc.ww[t][u][r];
+            }
+    hw::block_sync();
+    float* out = p.partial + (long)wg * 2 * HP * HP;
+    for (int idx = wave * 64 + lane; idx < 2 * HP * HP; idx += nwave * 64) {
+        float s = 0.f;
+        for (int v = 0; v < nwave; ++v) s += ((const float*)(lds_all + v * PER_WAVE + TILE_OFF))[idx];
+        out[idx] = s;
+    }
+}
+
+}  // namespace amix

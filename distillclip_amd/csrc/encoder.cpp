@@ -141,6 +141,7 @@ struct Work {
     bf16_t *dbig, *dh, *dqkv, *dR, *dS, *dout;   // dbig [R][M, F], dqkv [R][M, 3D]
     float* tok_sum; float* demb;           // [N, D] ; compressed: [M, rank] f32
     float* wg_dummy;                       // [2, H, H] sink for conv_l / conv_w gradients when those parameters are frozen
+    float* mix_ws; size_t mix_ws_bytes;    // per-workgroup weight-gradient partials of dclip_attn_mix_bwd
     size_t bytes;
 };
 
@@ -199,9 +200,12 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
         w.tok_sum = b.take<float>((int64_t)N * D);
         w.wg_dummy = b.take<float>(2 * p.H * p.H);
+        w.mix_ws_bytes = p.c.head_mix ? dclip_attn_mix_bwd_workspace_bytes(p.H) : 0;
+        w.mix_ws = w.mix_ws_bytes ? (float*)b.take<char>(w.mix_ws_bytes) : nullptr;
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {
         w.G = nullptr; w.Gb = nullptr; w.gb_f2 = w.gb_pr = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr; w.wg_dummy = nullptr;
+        w.mix_ws = nullptr; w.mix_ws_bytes = 0;
     }
     w.bytes = b.off;
 }
@@ -217,13 +221,11 @@ inline bool fused_student_attn(const Plan& p, int64_t N) {
     return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_student_fwd_supported(p.H, N, p.hd) != 0;
 }
 
-// DCLIP_ATTN_MIX=1 (opt-in): head-mixing students whose shape has a register-resident instantiation (attention_mix.hip) keep S,
-// A, P, dR out of HBM; forward and backward must agree (the backward recomputes from qkv + the forward's softmax statistics).
-// Off by default: correct (kernel-level and tower-level parity tests run it), but at 2 waves per SIMD the register mixes are
-// bound by the weight-operand fetch, not by the VALU: 247 / 1190 us (forward / backward score stage, text student, B = 512)
-// against 202 / 247 us for the unfused kernels (tools/diag/attn_mix_bench.py).
+// Head-mixing students whose shape has an instantiation of the register-resident score stage (attention_mix.hip: both head mixes
+// on the matrix pipe) keep S, A, P, dR out of HBM; forward and backward must agree (the backward recomputes from qkv + the forward's
+// softmax statistics), hence one predicate for both.  DCLIP_ATTN_MIX=0 selects the unfused kernels (attn_nt -> softmax -> ...).
 inline bool mix_attn(const Plan& p, int64_t N) {
-    static const int mode = [] { const char* e = getenv("DCLIP_ATTN_MIX"); return e ? atoi(e) : 0; }();
+    static const int mode = [] { const char* e = getenv("DCLIP_ATTN_MIX"); return e ? atoi(e) : 1; }();
     return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_mix_supported(p.H, N, p.hd) != 0;
 }
 
@@ -512,7 +514,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (wl && mix_attn(p, N)) {
             float* gl = GR(sr.cl) ? GR(sr.cl) : w.wg_dummy;
             float* gw = GR(sr.cw) ? GR(sr.cw) : w.wg_dummy + H * H;
-            CK(dclip_attn_mix_bwd(s.qkv, 3 * D, dctx, D, wl, ww, s.stats, w.dS, gl, gw, B, H, N, Np, hd, scale, st));
+            CK(dclip_attn_mix_bwd(s.qkv, 3 * D, dctx, D, wl, ww, s.stats, w.dS, gl, gw, w.mix_ws, w.mix_ws_bytes, B, H, N, Np, hd, scale, st));
         } else {
             CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));               // dR = dO V^T
             CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,

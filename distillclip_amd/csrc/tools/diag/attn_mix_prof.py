@@ -1,0 +1,39 @@
+"""dclip_attn_mix_fwd / _bwd alone on the step's two student shapes (preallocated outputs, no torch work in the timed loop);
+run it under rocprofv3 (--kernel-trace --stats, or --pmc ...) to read kernel time / counters.  argv: [reps] [which: all|img|txt]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from distillclip_amd._lib import lib
+from distillclip_amd.ops import _p, _stream
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+which = sys.argv[2] if len(sys.argv) > 2 else 'all'
+shapes = [(512, 50, 24, 32)] * (which in ('all', 'img')) + [(512, 77, 12, 64)] * (which in ('all', 'txt'))
+for B, N, H, hd in shapes:
+    D = H * hd
+    Np = (N + 7) // 8 * 8
+    g = torch.Generator(device='cpu').manual_seed(1)
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 0.7).bfloat16().cuda()
+    dctx = torch.randn(B * N, D, generator=g).bfloat16().cuda()
+    wl = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).cuda()
+    ww = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).cuda()
+    scale = hd ** -0.5
+    R = torch.empty(B, H, N, Np, dtype=torch.bfloat16, device='cuda')
+    dS = torch.empty_like(R)
+    lse = torch.empty(B, H, N, device='cuda')
+    dwl, dww = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
+    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(H), dtype=torch.uint8, device='cuda')
+    fwd = lambda: lib().dclip_attn_mix_fwd(_p(qkv), 3 * D, _p(wl), _p(ww), _p(R), _p(lse), B, H, N, Np, hd, scale, _stream())
+    bwd = lambda: lib().dclip_attn_mix_bwd(_p(qkv), 3 * D, _p(dctx), D, _p(wl), _p(ww), _p(lse), _p(dS), _p(dwl), _p(dww), _p(ws), ws.numel(),
+                                           B, H, N, Np, hd, scale, _stream())
+    for name, fn in (('fwd', fwd), ('bwd', bwd)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        print(f'B {B} N {N} H {H} hd {hd} mix {name}: {a.elapsed_time(b) / reps * 1e3:8.1f} us', flush=True)

@@ -202,7 +202,7 @@ def attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale):
     """register-resident head-mixed attention scores (include/dclip.h: dclip_attn_mix_fwd) -> (R bf16 [B,H,N,Np], lse f32 [B,H,N])"""
     _chk(qkv, wl, ww)
     Np = (N + 7) // 8 * 8
-    r = torch.zeros((B, H, N, Np), dtype=torch.bfloat16, device=qkv.device)
+    r = torch.full((B, H, N, Np), float('nan'), dtype=torch.bfloat16, device=qkv.device)    # the kernel writes every element
     stats = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     lib().dclip_attn_mix_fwd(_p(qkv), qkv.stride(0), _p(wl), _p(ww), _p(r), _p(stats), B, H, N, Np, hd, scale, _stream())
     return r, stats
@@ -212,7 +212,8 @@ def attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, stats, scale, dwl, dww):
     """-> dS bf16 [B,H,N,Np] (gradient of the scaled pre-mix scores); dwl / dww += (include/dclip.h: dclip_attn_mix_bwd)"""
     _chk(qkv, d_ctx, wl, ww, stats, dwl, dww)
     Np = (N + 7) // 8 * 8
-    ds = torch.zeros((B, H, N, Np), dtype=torch.bfloat16, device=qkv.device)
+    ds = torch.full((B, H, N, Np), float('nan'), dtype=torch.bfloat16, device=qkv.device)  # the kernel writes every element
+    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(H), dtype=torch.uint8, device=qkv.device)
     lib().dclip_attn_mix_bwd(_p(qkv), qkv.stride(0), _p(d_ctx), d_ctx.stride(0), _p(wl), _p(ww), _p(stats), _p(ds), _p(dwl), _p(dww),
-                             B, H, N, Np, hd, scale, _stream())
+                             _p(ws), ws.numel(), B, H, N, Np, hd, scale, _stream())
     return ds

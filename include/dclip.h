@@ -125,23 +125,30 @@ int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const f
                            int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 
 /*
- * Head-mixed student attention with the score tensors kept in registers (attention_mix.hip; reference
- * weight_share_model.py:101-125).  One wave per (sample, 16 query rows): S = scale q k^T, A = conv_l(S), P = softmax(A),
- * R = conv_w(P) are produced and consumed in the MFMA accumulator layout; only R (bf16 [B,H,N,Np], pad columns zero) and the
- * softmax statistics (f32 [B,H,N]: log-sum-exp of every row of A) are stored.  The backward recomputes S, A, P from the
- * packed qkv rows, forms dR = dO v^T on the fly and writes dS (bf16, gradient of the scaled pre-mix scores) plus
- * dWl / dWw += [H,H] (f32 atomics).  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
+ * Head-mixed student attention, score stage, with the score tensors kept in registers and BOTH head mixes on the matrix pipe
+ * (attention_mix.hip + attn_mix_wave.h; reference weight_share_model.py:101-125).  One wave per (sample, 16 query rows):
+ * S = scale q k^T comes out of block-diagonal MFMAs with lane group g holding head 4s + g, so that the packed accumulator
+ * registers are the B operand of A = conv_l(S) with the mix matrix as the A operand; P = softmax(A) is a per-register exp2
+ * against the log-sum-exp that enters as the initial accumulator; R = conv_w(P) contracts over the accumulator's row index
+ * (no lane movement).  Only R (bf16 [B,H,N,Np], pad columns zero) and the softmax statistics (f32 [B,H,N]: log-sum-exp of
+ * every row of A) are stored.  The backward recomputes S, A, P from the packed qkv rows, forms dR = dO v^T on the fly and
+ * writes dS (bf16, gradient of the scaled pre-mix scores); dWl / dWw += [H,H] leave as one partial tile per workgroup in
+ * `workspace` (dclip_attn_mix_bwd_workspace_bytes(H) bytes, 16-byte aligned) summed by a second launch: no atomics, run-to-run
+ * identical.  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
  *   forward   dclip_attn_mix_fwd -> dclip_attn_nn(R, v) ;   backward   dclip_attn_tn(R, dO) -> dV, dclip_attn_mix_bwd -> dS,
  *             dclip_attn_nn(dS, k) -> dQ, dclip_attn_tn(dS, q) -> dK.
  * Replaces dclip_attn_nt + dclip_attn_softmax_fwd and dclip_attn_nt + dclip_attn_softmax_bwd (S f32, P, dR never stored).
- * dclip_attn_mix_supported: H in {2, 4, 8, 12}, hd in {32, 64}, N <= 128 (other shapes use the unfused kernels).
+ * Mix operands are f16 in the forward (the precision of the reference's fp16 autocast) and bf16 on the gradient side.
+ * dclip_attn_mix_supported: H in {2, 4, 8, 12} with hd in {32, 64}, or H = 24 with hd = 32; N <= 128 (other shapes use the
+ * unfused kernels).
  */
 int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd);
+size_t dclip_attn_mix_bwd_workspace_bytes(int64_t H);
 int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* R, float* stats, int64_t B, int64_t H,
                        int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo, const float* Wl, const float* Ww,
-                       const float* stats, void* dS, float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np,
-                       int64_t hd, float scale, void* stream);
+                       const float* stats, void* dS, float* dWl, float* dWw, void* workspace, size_t ws_bytes, int64_t B, int64_t H,
+                       int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Embedding-side helpers (HBM-bound).

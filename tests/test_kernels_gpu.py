@@ -208,9 +208,12 @@ def test_fused_student_attention_forward(B, N, H, hd):
 
 
 @pytest.mark.parametrize('B,N,H,hd', [(3, 77, 12, 64), (2, 17, 4, 32), (3, 13, 2, 64), (2, 50, 12, 32), (1, 101, 8, 64), (5, 16, 4, 64),
-                                      (2, 128, 12, 64), (1, 1, 2, 64)])
+                                      (2, 128, 12, 64), (1, 1, 2, 64), (3, 50, 24, 32), (2, 101, 24, 32), (9, 77, 12, 64), (70, 50, 24, 32)])
 def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
-    """dclip_attn_mix_fwd / _bwd (attention_mix.hip; reference weight_share_model.py:101-125): S, A, P, dR live only in registers.
+    """dclip_attn_mix_fwd / _bwd (attention_mix.hip; reference weight_share_model.py:101-125): S, A, P, dR live only in registers
+    and both head mixes run on the matrix pipe (f16 operands in the forward -- the precision the reference's fp16 autocast gives
+    conv_l / conv_w -- hence 1e-3 on the log-sum-exp rows; bf16 on the gradient side).  Shapes include both shipped students
+    (H = 24 / hd = 32 / N = 50 and 101; H = 12 / hd = 64 / N = 77) and a batch that needs more than one persistent round.
     Forward R and the softmax statistics against an fp32 graph on the same bf16 q, k; backward dS, dW_l, dW_w against autograd of
     that graph with dR = dO v^T; and the whole attention (ctx, dq, dk, dv through the unchanged nn / tn products) against the
     unfused three-kernel path on the same inputs."""
@@ -228,7 +231,7 @@ def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
     a = torch.einsum('gh,bhij->bgij', wlr, sr)
     rr = torch.einsum('gh,bhij->bgij', wwr, a.softmax(-1))
     _close(R[..., :N], rr, 5e-3, 'R')
-    _close(lse, torch.logsumexp(a, -1), 1e-5, 'log-sum-exp rows')
+    _close(lse, torch.logsumexp(a, -1), 1e-3, 'log-sum-exp rows')
     assert torch.count_nonzero(R[..., N:]) == 0
     # backward of the score stage
     d_ctx = _randn((B * N, D), 54, 1.0, torch.bfloat16)

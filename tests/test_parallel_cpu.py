@@ -1,6 +1,5 @@
 """world_size-2 rehearsal (gloo, CPU) of the data-parallel gradient exchange: same call pattern as the RCCL path."""
 import os
-import socket
 
 import pytest
 import torch
@@ -8,48 +7,41 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _run_ranks(target, world=2, timeout=120, attempts=2):
-    """spawn `world` rank processes of `target(rank, world, port, q)` and collect one queue item per rank.  The rendezvous port
-    comes from bind-then-close, which another process can grab in between: one retry on a fresh port covers that race."""
+def _run_ranks(target, world=2, timeout=120):
+    """spawn `world` rank processes of `target(rank, world, rdzv, q)` and collect one queue item per rank.  Rendezvous is a
+    FileStore in a private temporary directory: no port is picked, so there is no bind-then-close race and NO retry -- a queue
+    timeout or a non-zero rank exit fails the test on the first attempt."""
     import queue as _queue
+    import shutil
+    import tempfile
     ctx = mp.get_context('spawn')
-    last = None
-    for _ in range(attempts):
-        q = ctx.Queue()
-        port = _free_port()
-        ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
-        for p in ps:
-            p.start()
+    q = ctx.Queue()
+    d = tempfile.mkdtemp(prefix='dclip_rdzv_')
+    ps = [ctx.Process(target=target, args=(r, world, os.path.join(d, 'store'), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    try:
         try:
             res = [q.get(timeout=timeout) for _ in ps]
-        except _queue.Empty as e:
-            last = e
-            for p in ps:
-                if p.is_alive():
-                    p.terminate()
-                p.join(timeout=30)
-            continue
+        except _queue.Empty:
+            raise AssertionError(f'ranks did not report within {timeout} s (exit codes so far {[p.exitcode for p in ps]})')
         codes = []
         for p in ps:
             p.join(timeout=60)
             codes.append(p.exitcode)
-        if all(c == 0 for c in codes):
-            return res
-        last = AssertionError(f'rank exit codes {codes}')
-    raise last
+        assert all(c == 0 for c in codes), f'rank exit codes {codes}'
+        return res
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+        shutil.rmtree(d, ignore_errors=True)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
     from distillclip_amd.parallel import GradSync
     sync = GradSync(bucket_elems=1000)              # several buckets + a ragged tail
     g = torch.arange(3333, dtype=torch.float32) * (rank + 1)
@@ -69,9 +61,9 @@ def test_grad_sync_averages_flat_buffers_world2():
         assert torch.allclose(g, want_g) and torch.allclose(h, torch.full((17,), 0.5))
 
 
-def _gather_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _gather_worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
     from distillclip_amd.parallel import gather_embeddings
     a = torch.full((3, 4), float(rank)) + torch.arange(4)
     b = torch.full((3, 2), 10.0 * rank)
@@ -139,9 +131,9 @@ def test_sharded_loss_equals_reference_ddp_semantics():
     assert gi0.shape == (4, 32) and gi1.shape == (4, 32)
 
 
-def _gather_rows_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _gather_rows_worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
     from distillclip_amd.metrics import gather_rows
     x = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank
     q.put((rank, gather_rows(x).clone()))
@@ -214,9 +206,9 @@ _BUCKETS = [(64 * 34, 64 * 40), (64 * 20, 64 * 34), (64 * 12, 64 * 20), (64 * 8,
 _TRAINABLE = [[64 * 2, 64 * 8], [64 * 12, 64 * 25], [64 * 26, 64 * 40]]      # frozen: part of the embedding, bucket 3, one segment
 
 
-def _sharded_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _sharded_worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
     from distillclip_amd.parallel import GradSync
     from distillclip_amd.optim import FusedAdamW
     FusedAdamW._adamw = _torch_adamw
@@ -287,6 +279,10 @@ def test_shard_plan_rejects_indivisible_world():
     assert (o0, o1) == (b0 + (b1 - b0) // 2, b1) and off == 0
 
 
+def _launcher_env():
+    return {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'DCLIP_RDZV_FILE')}
+
+
 def test_bench_self_launch_dry_run():
     """`python bench.py --gpus 2 --dry-launch`: the parent starts two rank processes before touching any GPU and relays rank 0's
     JSON line; a non-zero exit of a rank propagates."""
@@ -294,22 +290,72 @@ def test_bench_self_launch_dry_run():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env = _launcher_env()
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch'], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
-    assert out == {'dry_launch': True, 'n_gpus': 2, 'backend': 'gloo'}
+    assert out == {'dry_launch': True, 'n_gpus': 2, 'ranks_seen': 2, 'backend': 'gloo'}
     # a failing rank (WORLD_SIZE mismatch is impossible here, so ask for an unknown config) -> non-zero exit of the launcher
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch', '--config', 'nope'], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
 
 
-def _ragged_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def test_launcher_rendezvous_20_times_without_retry():
+    """The launcher's rendezvous (FileStore in a private directory: no port to race for) 20 times in a row from one process, every
+    run on its first and only attempt."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dclip_bench_launcher', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = dict(os.environ)
+    try:
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'DCLIP_RDZV_FILE'):
+            os.environ.pop(k, None)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        keep = os.dup(1)
+        os.dup2(devnull, 1)                       # rank 0's JSON line (inherited stdout) is not this test's output
+        try:
+            codes = [bench.launch_ranks(2, ['--gpus', '2', '--dry-launch'], timeout_s=240.0, grace_s=60.0) for _ in range(20)]
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+            os.close(devnull)
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
+    assert codes == [0] * 20, codes
+
+
+def test_launcher_deadline_ends_a_hung_rank():
+    """A rank that never exits (stuck after the collective) must not block the launcher: once the first rank has exited the others
+    get --launch-grace seconds, then are terminated and the launcher exits non-zero."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_launcher_env(), DCLIP_DRY_HANG_RANK='1')
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch', '--launch-grace', '5',
+                        '--launch-timeout', '120'], env=env, capture_output=True, text=True, timeout=300)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and 'still running' in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert dt < 90, dt
+    # ... and the overall deadline alone (every rank hangs, nobody exits) does the same
+    env = dict(_launcher_env(), DCLIP_DRY_HANG_RANK='all')
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch', '--launch-timeout', '20'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'deadline' in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert time.monotonic() - t0 < 120
+
+
+def _ragged_worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
     from distillclip_amd.parallel import check_equal_batch
     check_equal_batch(8, torch.device('cpu'))                 # equal: passes on every rank
     try:

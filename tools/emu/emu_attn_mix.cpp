@@ -1,0 +1,206 @@
+// CPU check of the lane / register index maps of distillclip_amd/csrc/attn_mix_wave.h (head-mixed student attention with the mixes on
+// the matrix pipe): the per-wave device code runs on the 64-lane emulation of wave_emu.h and is compared with a plain f64 loop nest
+// of the reference's arithmetic (model/component/weight_share_model.py:101-125: scale q k^T -> conv_l -> softmax -> conv_w) and its
+// hand-derived backward.  Test infrastructure only (see wave_emu.h).
+//
+//   build:  clang++ -O2 -std=c++17 tools/emu/emu_attn_mix.cpp -o /tmp/emu_attn_mix -lpthread
+//   run:    /tmp/emu_attn_mix            (exit code 0 = every case within tolerance)
+#include "wave_emu.h"
+
+#include "../../distillclip_amd/csrc/attn_mix_wave.h"
+
+#include <thread>
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 12345) {}
+    double uni() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; }
+    double normal() { const double u = uni() + 1e-12, v = uni(); return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v); }
+};
+
+double rel_l2(const std::vector<double>& got, const std::vector<double>& ref) {
+    double n = 0, d = 0;
+    for (size_t i = 0; i < ref.size(); ++i) { d += (got[i] - ref[i]) * (got[i] - ref[i]); n += ref[i] * ref[i]; }
+    return sqrt(d / (n > 0 ? n : 1));
+}
+
+alignas(16) static const unsigned short zero_page[1024] = {};
+
+template <int H, int HD>
+int run_case(int B, int N, uint64_t seed, double score_gain) {
+    using C = amix::Cfg<H, HD>;
+    constexpr int D = H * HD, HP = C::HP;
+    const int Np = (N + 7) / 8 * 8, QT = (N + 15) / 16;
+    const long ld = 3 * D;
+    const float scale = 1.f / sqrtf((float)HD);
+    Rng rng(seed);
+    std::vector<bf16_t> qkv((size_t)B * N * ld), dO((size_t)B * N * D);
+    for (auto& x : qkv) x = (bf16_t)(float)(0.7 * score_gain * rng.normal());
+    for (auto& x : dO) x = (bf16_t)(float)rng.normal();
+    std::vector<float> Wl(H * H), Ww(H * H);
+    for (int g = 0; g < H; ++g)
+        for (int h = 0; h < H; ++h) {
+            Wl[g * H + h] = (g == h ? 1.f : 0.f) + 0.15f * (float)rng.normal();
+            Ww[g * H + h] = (g == h ? 1.f : 0.f) + 0.15f * (float)rng.normal();
+        }
+
+    // ---- f64 reference ---------------------------------------------------------------------------------------------------------
+    const size_t SN = (size_t)B * H * N * N;
+    std::vector<double> S(SN), A(SN), P(SN), Rr(SN), lse((size_t)B * H * N), dR(SN), dP(SN), dA(SN), dSr(SN), dWl(H * H, 0.0), dWw(H * H, 0.0);
+    auto at = [&](int b, int h, int i, int j) { return (((size_t)b * H + h) * N + i) * N + j; };
+    auto QKV = [&](int b, int tok, int which, int h, int d) { return (double)(float)qkv[((size_t)b * N + tok) * ld + which * D + h * HD + d]; };
+    for (int b = 0; b < B; ++b) {
+        for (int h = 0; h < H; ++h)
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) {
+                    double s = 0, dr = 0;
+                    for (int d = 0; d < HD; ++d) {
+                        s += QKV(b, i, 0, h, d) * QKV(b, j, 1, h, d);
+                        dr += (double)(float)dO[((size_t)b * N + i) * D + h * HD + d] * QKV(b, j, 2, h, d);
+                    }
+                    S[at(b, h, i, j)] = s * scale;
+                    dR[at(b, h, i, j)] = dr;
+                }
+        for (int g = 0; g < H; ++g)
+            for (int i = 0; i < N; ++i) {
+                double mx = -1e300;
+                for (int j = 0; j < N; ++j) {
+                    double a = 0;
+                    for (int h = 0; h < H; ++h) a += (double)Wl[g * H + h] * S[at(b, h, i, j)];
+                    A[at(b, g, i, j)] = a;
+                    mx = fmax(mx, a);
+                }
+                double sum = 0;
+                for (int j = 0; j < N; ++j) sum += exp(A[at(b, g, i, j)] - mx);
+                lse[((size_t)b * H + g) * N + i] = mx + log(sum);
+                for (int j = 0; j < N; ++j) P[at(b, g, i, j)] = exp(A[at(b, g, i, j)] - mx) / sum;
+            }
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                for (int g = 0; g < H; ++g) {
+                    double r = 0;
+                    for (int h = 0; h < H; ++h) r += (double)Ww[g * H + h] * P[at(b, h, i, j)];
+                    Rr[at(b, g, i, j)] = r;
+                }
+                for (int h = 0; h < H; ++h) {
+                    double v = 0;
+                    for (int g = 0; g < H; ++g) v += (double)Ww[g * H + h] * dR[at(b, g, i, j)];
+                    dP[at(b, h, i, j)] = v;
+                }
+            }
+        for (int h = 0; h < H; ++h)
+            for (int i = 0; i < N; ++i) {
+                double del = 0;
+                for (int j = 0; j < N; ++j) del += P[at(b, h, i, j)] * dP[at(b, h, i, j)];
+                for (int j = 0; j < N; ++j) dA[at(b, h, i, j)] = P[at(b, h, i, j)] * (dP[at(b, h, i, j)] - del);
+            }
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j)
+                for (int h = 0; h < H; ++h) {
+                    double v = 0;
+                    for (int g = 0; g < H; ++g) v += (double)Wl[g * H + h] * dA[at(b, g, i, j)];
+                    dSr[at(b, h, i, j)] = v;
+                }
+        for (int g = 0; g < H; ++g)
+            for (int h = 0; h < H; ++h) {
+                double a = 0, w = 0;
+                for (int i = 0; i < N; ++i)
+                    for (int j = 0; j < N; ++j) { a += dA[at(b, g, i, j)] * S[at(b, h, i, j)]; w += dR[at(b, g, i, j)] * P[at(b, h, i, j)]; }
+                dWl[g * H + h] += a; dWw[g * H + h] += w;
+            }
+    }
+
+    // ---- emulated forward -----------------------------------------------------------------------------------------------------
+    const size_t RN = (size_t)B * H * N * Np;
+    std::vector<bf16_t> Rk(RN), dSk(RN);
+    for (auto& x : Rk) x = (bf16_t)123.f;            // poison: every element up to Np must be written
+    for (auto& x : dSk) x = (bf16_t)123.f;
+    std::vector<float> stats((size_t)B * H * N, -7.f);
+    amix::FwdArgs fa{qkv.data(), ld, Wl.data(), Ww.data(), Rk.data(), stats.data(), B, N, Np, QT, scale};
+    const int nitem = B * QT, nwgf = (nitem + 3) / 4;
+    long ncoll = 0;
+    {
+        std::vector<std::thread> th;
+        std::vector<long> coll(nwgf, 0);
+        for (int wg = 0; wg < nwgf; ++wg)
+            th.emplace_back([&, wg] {
+                std::vector<char> lds(4 * amix::fwd_lds_per_wave<C>() + 16, (char)0x7f);
+                char* l16 = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+                emu::run_group(256, [&](int t) {
+                    const int lane = t & 63, wave = t >> 6, item = wg * 4 + wave;
+                    if (item >= nitem) return;
+                    char* mine = l16 + wave * amix::fwd_lds_per_wave<C>();
+                    amix::zero_block_init<C>(mine, lane);
+                    amix::FwdWeights<C> w;
+                    amix::fwd_load_weights<C>(fa, lane, w);
+                    amix::fwd_item<C>(fa, item / QT, item % QT, lane, w, mine, (const bf16_t*)zero_page);
+                });
+            });
+        for (auto& t : th) t.join();
+        (void)coll; (void)ncoll;
+    }
+    // ---- emulated backward (persistent workgroups + the partial-sum reduction) ----------------------------------------------------
+    const int nwgb = nitem >= 12 ? 3 : 1;
+    std::vector<float> partial((size_t)nwgb * 2 * HP * HP, -1.f);
+    amix::BwdArgs ba{qkv.data(), ld, dO.data(), (long)D, Wl.data(), Ww.data(), stats.data(), dSk.data(), partial.data(), B, N, Np, QT, scale};
+    {
+        std::vector<std::thread> th;
+        for (int wg = 0; wg < nwgb; ++wg)
+            th.emplace_back([&, wg] {
+                std::vector<char> lds(4 * amix::bwd_lds_per_wave<C>() + 16, (char)0x7f);
+                char* l16 = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+                emu::run_group(256, [&](int t) { amix::bwd_wave<C>(ba, wg, nwgb, t >> 6, 4, t & 63, l16, (const bf16_t*)zero_page); });
+            });
+        for (auto& t : th) t.join();
+    }
+    std::vector<double> gWl(H * H, 0.0), gWw(H * H, 0.0);
+    for (int wg = 0; wg < nwgb; ++wg)
+        for (int g = 0; g < H; ++g)
+            for (int h = 0; h < H; ++h) {
+                gWl[g * H + h] += partial[((size_t)wg * 2 + 0) * HP * HP + g * HP + h];
+                gWw[g * H + h] += partial[((size_t)wg * 2 + 1) * HP * HP + g * HP + h];
+            }
+
+    // ---- compare ---------------------------------------------------------------------------------------------------------------
+    std::vector<double> gR(SN), gS(SN), glse((size_t)B * H * N);
+    int bad_pad = 0;
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h)
+            for (int i = 0; i < N; ++i) {
+                for (int j = 0; j < Np; ++j) {
+                    const size_t o = (((size_t)b * H + h) * N + i) * Np + j;
+                    if (j < N) { gR[at(b, h, i, j)] = (double)(float)Rk[o]; gS[at(b, h, i, j)] = (double)(float)dSk[o]; }
+                    else if ((float)Rk[o] != 0.f || (float)dSk[o] != 0.f) ++bad_pad;
+                }
+                glse[((size_t)b * H + h) * N + i] = stats[((size_t)b * H + h) * N + i];
+            }
+    const double eR = rel_l2(gR, Rr), eL = rel_l2(glse, lse), eS = rel_l2(gS, dSr), eWl = rel_l2(gWl, dWl), eWw = rel_l2(gWw, dWw);
+    // R and dS are stored as bf16 (2^-9 relative); the f16 mix operands add ~2^-11 |S| to the pre-softmax scores
+    const bool ok = eR < 6e-3 && eL < 1e-3 && eS < 1.2e-2 && eWl < 1.5e-2 && eWw < 1.5e-2 && bad_pad == 0;
+    printf("H=%2d hd=%2d B=%d N=%3d gain=%.1f : R %.2e  lse %.2e  dS %.2e  dWl %.2e  dWw %.2e  pad %d  %s\n", H, HD, B, N, score_gain, eR, eL, eS,
+           eWl, eWw, bad_pad, ok ? "ok" : "FAIL");
+    return ok ? 0 : 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const bool full = argc > 1 && !strcmp(argv[1], "full");
+    int bad = 0;
+    bad += run_case<4, 32>(2, 17, 1, 1.0);
+    bad += run_case<2, 64>(3, 13, 2, 1.0);
+    bad += run_case<8, 32>(2, 9, 12, 1.0);
+    bad += run_case<12, 64>(1, 21, 3, 1.0);
+    bad += run_case<24, 32>(1, 19, 4, 1.0);
+    bad += run_case<8, 64>(1, 1, 5, 1.0);
+    bad += run_case<4, 32>(1, 40, 6, 4.0);        // peaked rows: the running reference of the softmax statistics has to move
+    if (full) {
+        bad += run_case<24, 32>(3, 50, 7, 1.0);
+        bad += run_case<12, 64>(3, 77, 8, 1.0);
+        bad += run_case<24, 32>(1, 101, 9, 1.0);
+    }
+    printf(bad ? "FAILED: %d case(s)\n" : "all cases ok\n", bad);
+    return bad ? 1 : 0;
+}
