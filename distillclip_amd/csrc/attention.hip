@@ -27,7 +27,18 @@ struct AttnMM {
     void* C; int64_t ldc;            // NT: [B,H,N,Np] (f32 or bf16, ldc = Np) ; NN/TN: token-major bf16
     int B, H, N, Np, hd;
     float alpha;
+    int a_blocked;                   // NN/TN: A is quad-blocked [B,H,Np/4,N,4] (attention_mix.hip) instead of row-major [B,H,N,Np]
 };
+
+// 8 consecutive columns j0 .. j0 + 7 (j0 % 8 == 0) of row i of a score-like matrix of one (b, h): row-major rows of Np, or the
+// quad-blocked layout of the register-resident score stage (element (i, j) at ((j >> 2) * N + i) * 4 + (j & 3)): two 8-byte halves
+__device__ __forceinline__ u32x4 load_a8(const bf16_t* A, int64_t lda, int N, int blocked, int i, int j0) {
+    if (!blocked) return *(const u32x4*)(A + (int64_t)i * lda + j0);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 lo = *(const u32x2*)(A + ((int64_t)(j0 >> 2) * N + i) * 4);
+    const u32x2 hi = *(const u32x2*)(A + ((int64_t)((j0 >> 2) + 1) * N + i) * 4);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 
 __device__ __forceinline__ bf16x8 zero_frag() {
     bf16x8 z;
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
 #pragma unroll
         for (int ks = 0; ks < KSM; ++ks) {
             const int j0 = ks * 32 + fk;
-            dst[ks] = (ks < nks && j0 < p.Np) ? *(const bf16x8*)(A + (int64_t)ia * p.lda + j0) : zero_frag();
+            dst[ks] = (ks < nks && j0 < p.Np) ? __builtin_bit_cast(bf16x8, load_a8(A, p.lda, p.N, p.a_blocked, ia, j0)) : zero_frag();
         }
     };
     load_a(0, af);
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
         for (int k = 0; k < ACH; ++k) {
             const int idx = k * 64 + lane, r = idx / acpr, c = idx - r * acpr;
             ra[k] = u32x4{0u, 0u, 0u, 0u};
-            if (r < 32 && ch * 32 + r < p.N) ra[k] = *(const u32x4*)(A + (int64_t)(ch * 32 + r) * p.lda + c * 8);
+            if (r < 32 && ch * 32 + r < p.N) ra[k] = load_a8(A, p.lda, p.N, p.a_blocked, ch * 32 + r, c * 8);
         }
 #pragma unroll
         for (int k = 0; k < BCH; ++k) {
@@ -1153,7 +1164,7 @@ extern "C" int dclip_trace_attn_stamps(void* buf) { g_attn_stamps = (unsigned lo
 
 extern "C" int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B,
                              int64_t H, int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
-    AttnMM p{A, lda, (const bf16_t*)Bm, ldb, C, Np, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+    AttnMM p{A, lda, (const bf16_t*)Bm, ldb, C, Np, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha, 0};
     if (int rc = check_mm(p, "dclip_attn_nt")) return rc;
     DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "dclip_attn_nt: token-major strides must be multiples of 8");
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + (out_f32 ? 4.0 : 2.0) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 1);
@@ -1170,8 +1181,8 @@ extern "C" int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t
 }
 
 extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H,
-                             int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
-    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+                             int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream) {
+    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha, a_blocked};
     if (int rc = check_mm(p, "dclip_attn_nn")) return rc;
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 2);
     const dim3 grid((unsigned)((B * H + 3) / 4));
@@ -1183,8 +1194,8 @@ extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C
 }
 
 extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H,
-                             int64_t N, int64_t Np, int64_t hd, float alpha, void* stream) {
-    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha};
+                             int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream) {
+    AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha, a_blocked};
     if (int rc = check_mm(p, "dclip_attn_tn")) return rc;
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 3);
     const dim3 grid((unsigned)((B * H + 3) / 4));

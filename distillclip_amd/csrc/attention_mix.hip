@@ -30,6 +30,8 @@ DEVFN bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // compiler from moving accesses across it
 DEVFN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 DEVFN void block_sync() { __syncthreads(); }
+DEVFN unsigned long long clock() { return __builtin_readcyclecounter(); }
+DEVFN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }    // no instruction moves across this point
 // LDS-DMA: 16 bytes per lane from the lane's own global address to (wave-uniform dst) + lane * 16; completion is tracked by vmcnt
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -42,11 +44,9 @@ template <int N> DEVFN void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n
 
 namespace {
 
-// the 48 lanes of a block-diagonal A operand that carry no row read zeros from here (one head row set: D <= 1024 bf16)
-__device__ __attribute__((aligned(16))) const unsigned short g_zero_page[1024] = {};
-
-template <int H, int HD>
-__global__ __launch_bounds__(256, 2) void attn_mix_fwd_kernel(amix::FwdArgs p) {
+// OCC = waves per SIMD the register allocation is held to (2: two workgroups per CU hide each other's latencies, at 256 registers)
+template <int H, int HD, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_mix_fwd_kernel(amix::FwdArgs p) {
     using C = amix::Cfg<H, HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -54,11 +54,17 @@ __global__ __launch_bounds__(256, 2) void attn_mix_fwd_kernel(amix::FwdArgs p) {
     const int item = blockIdx.x * 4 + wave;
     if (item >= p.B * p.QT) return;
     const int b = item / p.QT, it = item - b * p.QT;
+    const unsigned long long te = p.stamps ? hw::clock() : 0;
     char* lds = smem + wave * amix::fwd_lds_per_wave<C>();
     amix::zero_block_init<C>(lds, lane);
     amix::FwdWeights<C> w;
     amix::fwd_load_weights<C>(p, lane, w);
-    amix::fwd_item<C>(p, b, it, lane, w, lds, (const bf16_t*)g_zero_page);
+    if (p.stamps && lane == 0) {
+        p.stamps[12 * (long)item + 8] = hw::clock() - te;                          // zero block + weight fragments
+        p.stamps[12 * (long)item + 10] = __builtin_amdgcn_s_memrealtime();        // 100 MHz: wave start
+    }
+    amix::fwd_item<C>(p, b, it, lane, w, lds);
+    if (p.stamps && lane == 0) p.stamps[12 * (long)item + 11] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int H, int HD>
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_mix_bwd_kernel(amix::BwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    amix::bwd_wave<C>(p, blockIdx.x, gridDim.x, wave, 4, lane, smem, (const bf16_t*)g_zero_page);
+    amix::bwd_wave<C>(p, blockIdx.x, gridDim.x, wave, 4, lane, smem);
 }
 
 // dW[which][g, h] += mul * sum over the workgroups' partial tiles
@@ -83,6 +89,7 @@ __global__ void attn_mix_wgrad_reduce_kernel(const float* __restrict__ partial, 
 }
 
 constexpr int BWD_MAX_WG = 256;
+unsigned long long* g_fwd_stamps = nullptr;      // diagnostics only (tools/diag/attn_mix_prof.py)
 
 }  // namespace
 
@@ -106,6 +113,10 @@ extern "C" int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd) {
     return shape && H * hd <= 1024 && (H * hd) % 128 == 0 && N >= 1 && N <= 128;
 }
 
+// diagnostics: subsequent dclip_attn_mix_fwd launches of this process write 12 counts per (sample, 16-query tile) to `buf`
+// (u64 [B * ceil(N / 16)][12]: pass 1 total / ring wait / score MFMAs / per-key stage, then the same for pass 2); nullptr = off
+extern "C" void dclip_attn_mix_debug_stamps(void* buf) { g_fwd_stamps = (unsigned long long*)buf; }
+
 extern "C" size_t dclip_attn_mix_bwd_workspace_bytes(int64_t H) {
     const size_t HP = (size_t)((H + 15) / 16) * 16;
     return (size_t)BWD_MAX_WG * 2 * HP * HP * sizeof(float);
@@ -118,12 +129,18 @@ extern "C" int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, 
     DCLIP_REQUIRE(Np == ((N + 7) & ~(int64_t)7) && ld % 8 == 0 && ld >= 3 * H * hd && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)R % 16) == 0,
                   "dclip_attn_mix_fwd: misaligned buffers (Np = round_up(N, 8), 16-byte aligned qkv rows and R)");
     const int QT = (int)((N + 15) / 16);
-    amix::FwdArgs p{(const bf16_t*)qkv, (long)ld, Wl, Ww, (bf16_t*)R, stats, (int)B, (int)N, (int)Np, QT, scale};
+    amix::FwdArgs p{(const bf16_t*)qkv, (long)ld, Wl, Ww, (bf16_t*)R, stats, (int)B, (int)N, (int)Np, QT, scale, g_fwd_stamps};
     const dim3 grid((unsigned)((B * QT + 3) / 4));
     const double el = (double)B * H * N * Np;
     TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd + 8.0 * el * H, 2.0 * el + 4.0 * B * N * H * hd, stream, (int)(B * H), (int)N, (int)hd, 7);
-    MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
-                                           (hipStream_t)stream, p));
+    static const int occ = [] { const char* e = getenv("DCLIP_MIX_OCC"); return e ? atoi(e) : 2; }();
+    if (occ == 1) {
+        MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_, 1>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
+                                               (hipStream_t)stream, p));
+    } else {
+        MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_, 2>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
+                                               (hipStream_t)stream, p));
+    }
     return dclip_check_launch("dclip_attn_mix_fwd");
 }
 

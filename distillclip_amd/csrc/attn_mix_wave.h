@@ -53,10 +53,11 @@ constexpr float P_OFF = 1e30f;                   // "log-sum-exp" of rows that m
 struct FwdArgs {
     const bf16_t* qkv; long ld;                  // [B*N, 3D]: q | k | v, head h at column h * HD
     const float* Wl; const float* Ww;            // [H, H] conv_l / conv_w weights (f32 masters)
-    bf16_t* R;                                   // [B, H, N, Np] mixed probabilities, pad columns zero
+    bf16_t* R;                                   // mixed probabilities, quad-blocked [B, H, Np / 4, N, 4], pad columns zero
     float* stats;                                // [B, H, N] log-sum-exp (natural log) of row (b, h, i) of A
     int B, N, Np, QT;
     float scale;
+    unsigned long long* stamps;                  // diagnostics (nullable): 12 cycle counts per (sample, tile), see fwd_item
 };
 
 struct BwdArgs {
@@ -64,7 +65,7 @@ struct BwdArgs {
     const bf16_t* dO; long ldo;                  // [B*N, D] gradient of ctx
     const float* Wl; const float* Ww;
     const float* stats;
-    bf16_t* dS;                                  // [B, H, N, Np] gradient of the scaled pre-mix scores, pad columns zero
+    bf16_t* dS;                                  // gradient of the scaled pre-mix scores, quad-blocked like R, pad columns zero
     float* partial;                              // [workgroups][2][HP][HP] weight-gradient partial sums (dW_l, dW_w)
     int B, N, Np, QT;
     float scale;
@@ -82,7 +83,8 @@ DEVFN T8 weight_frag(int lane, int t, F elem) {
     for (int jj = 0; jj < 8; ++jj) {
         const int in = SLAYOUT ? 4 * jj + grp : 16 * (jj >> 2) + 4 * grp + (jj & 3);
         const bool ok = row < C::H && in < C::H && (!SLAYOUT || jj < C::NS);
-        f[jj] = (typename elem_of<T8>::type)(ok ? elem(row, in) : 0.f);
+        const float v = elem(row < C::H ? row : C::H - 1, in < C::H ? in : C::H - 1);      // unconditional: the loads overlap
+        f[jj] = (typename elem_of<T8>::type)(ok ? v : 0.f);
     }
     return f;
 }
@@ -108,7 +110,7 @@ DEVFN void load_col_frags(const bf16_t* mat, long ld, int tok, bool tok_ok, int 
 // A quad of token rows (4 x D bf16) is one stage, filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging) one quad
 // ahead of its use.  LDS-DMA writes lane-linear, so the layout is chosen on the SOURCE side: position (row r, chunk cp) of a stage
 // holds source chunk cp ^ r of row r0 + r, which puts the 4 rows of one head chunk on 4 different bank groups for the
-// ds_read_b128 fragment reads below.  Rows >= nrows are read from a zero page.
+// ds_read_b128 fragment reads below.
 template <class C>
 struct Ring {
     static constexpr int ROWB = C::D * 2;            // bytes of one token row (all heads)
@@ -118,15 +120,17 @@ struct Ring {
 };
 
 template <class C>
-DEVFN void stage_quad(const bf16_t* rows, long ld, int r0, int nrows, const bf16_t* zero_page, char* stage, int lane) {
+DEVFN void stage_quad(const bf16_t* rows, long ld, int r0, int nrows, char* stage, int lane) {
     constexpr int CPR = Ring<C>::CPR;
-#pragma unroll
+    const char* quad = (const char*)(rows + (long)r0 * ld);                      // wave-uniform base, 32-bit lane offsets
+    const int last = nrows - 1 - r0;                                              // rows past the end re-read the last row: the keys
+#pragma unroll                                                                    // they stand for are masked where they are consumed
     for (int k = 0; k < Ring<C>::NINST; ++k) {
         const int pos = k * 64 + lane;
         const int r = pos / CPR, cp = pos - r * CPR;
-        const int row = r0 + r;
-        const bf16_t* src = (row < nrows ? rows + (long)row * ld : zero_page) + ((cp ^ r) << 3);
-        hw::dma16(src, stage + k * 1024);
+        const int rr = r < last ? r : last;
+        const unsigned off = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)((cp ^ r) << 4);
+        hw::dma16(quad + off, stage + k * 1024);
     }
 }
 
@@ -140,24 +144,39 @@ DEVFN void bd_scores(const char* stage, const char* zeros, int lane, const bf16x
     const bool lane_ok = (c >> 2) == g4;
     const char* base = lane_ok ? stage + row * Ring<C>::ROWB + 16 * g4 * NC : zeros;
     const int x = lane_ok ? row : 0;
-    // fragment reads run AHEAD sets ahead of the MFMA chain that consumes them (one wave per SIMD: nothing else hides LDS latency)
-    constexpr int AHEAD = NS < 3 ? NS : 3;
-    bf16x8 kf[NS][NC];
-    auto fetch = [&](int s) {
-        const bool head_ok = (C::H % 4 == 0) || 4 * s + g4 < C::H;
-        const char* ps = head_ok ? base : zeros;
+    // Schedule (one or two waves per SIMD: the wave has to hide its own LDS latency).  The sets are cut into groups of 8 fragments;
+    // the reads of group g + 1 are issued before the MFMAs of group g, and inside a group the MFMAs go chunk-major, so that two
+    // MFMAs on the same accumulator are GS issues apart.  sched_fence() pins that order for the compiler.
+    constexpr int GS = (8 / NC) < NS ? (8 / NC) : NS;          // sets per group
+    constexpr int NG = (NS + GS - 1) / GS;
+    bf16x8 kf[2][GS][NC];
+    auto fetch = [&](int g, int buf) {
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) kf[s][ci] = *(const bf16x8*)(ps + 16 * (4 * s * NC + (ci ^ x)));
+        for (int u = 0; u < GS; ++u) {
+            const int s = g * GS + u;
+            if (s < NS) {
+                const bool head_ok = (C::H % 4 == 0) || 4 * s + g4 < C::H;
+                const char* ps = head_ok ? base : zeros;
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) kf[buf][u][ci] = *(const bf16x8*)(ps + 16 * (4 * s * NC + (ci ^ x)));
+            }
+        }
     };
 #pragma unroll
-    for (int s = 0; s < AHEAD; ++s) fetch(s);
+    for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0, 0);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (s + AHEAD < NS) fetch(s + AHEAD);
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+        hw::sched_fence();
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) a = hw::mfma_bf16(kf[s][ci], colf[s][ci], a);
-        acc[s] = a;
+        for (int ci = 0; ci < NC; ++ci)
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                const int s = g * GS + u;
+                if (s < NS) acc[s] = hw::mfma_bf16(kf[g & 1][u][ci], colf[s][ci], acc[s]);
+            }
+        hw::sched_fence();
     }
 }
 
@@ -166,12 +185,11 @@ template <class C, int NMAT>
 struct RowStream {
     const bf16_t* rows[NMAT];
     long ld; int nrows;
-    const bf16_t* zero_page;
     char* ring;
     int lane, par;
     DEVMEM void issue(int q, int pp) const {
 #pragma unroll
-        for (int m = 0; m < NMAT; ++m) stage_quad<C>(rows[m], ld, 4 * q, nrows, zero_page, ring + (2 * m + pp) * Ring<C>::STAGE, lane);
+        for (int m = 0; m < NMAT; ++m) stage_quad<C>(rows[m], ld, 4 * q, nrows, ring + (2 * m + pp) * Ring<C>::STAGE, lane);
     }
     // quad `next` is requested into the other parity, then everything older than that request has landed: the current quad
     DEVMEM void advance(int next) {
@@ -225,18 +243,24 @@ constexpr int fwd_lds_per_wave() { return Ring<C>::ROWB + 2 * Ring<C>::STAGE; } 
 // One (sample, 16-query tile): pass 1 = softmax statistics, pass 2 = P, R.  R is written as 16-byte groups of 8 keys.
 // lds: this wave's region (fwd_lds_per_wave bytes), its first ROWB bytes already zero.
 template <class C>
-DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<C>& w, char* lds, const bf16_t* zero_page) {
+DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<C>& w, char* lds) {
     constexpr int NS = C::NS, RT = C::RT, H = C::H, D = C::D;
     const int c = lane & 15, g4 = lane >> 4;
     const int N = p.N;
     const int i = it * 16 + c;
     const bool iok = i < N;
     const bf16_t* base = p.qkv + (long)b * N * p.ld;
+    const unsigned long long tq0 = p.stamps ? hw::clock() : 0;
     bf16x8 qf[NS][C::NC];
     load_col_frags<C>(base, p.ld, i, iok, lane, qf);
     const char* zeros = lds;
-    RowStream<C, 1> ks{{base + D}, p.ld, N, zero_page, lds + Ring<C>::ROWB, lane, 0};
+    RowStream<C, 1> ks{{base + D}, p.ld, N, lds + Ring<C>::ROWB, lane, 0};
     const int nq = (N + 3) >> 2;
+
+    // diagnostics: cycles spent waiting for the ring / in the score MFMAs / in the per-key stage, summed over the quads
+    const bool st = p.stamps != nullptr;
+    unsigned long long t_wait = 0, t_s = 0, t_i = 0, t0 = st ? hw::clock() : 0, tq = 0;
+    if (st && lane == 0) p.stamps[12 * ((long)b * p.QT + it) + 9] = t0 - tq0;          // query fragments
 
     // ---- pass 1: reference value from the first quad, then running sums with a lazy rescale ------------------------------------
     f32x4 m[RT], l[RT];
@@ -264,10 +288,13 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
     // TAIL (compile time) = the quad may reach past N: only that variant carries the per-key validity branches
     auto stats_quad = [&](auto tail_c, int q) {
         constexpr bool TAIL = decltype(tail_c)::value;
+        if (st) tq = hw::clock();
         ks.advance(q + 1 < nq ? q + 1 : 0);          // the last request is quad 0 of pass 2
+        if (st) { const unsigned long long t = hw::clock(); t_wait += t - tq; tq = t; }
         f32x4 sa[NS];
         bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
         ks.done();
+        if (st) { const unsigned long long t = hw::clock(); t_s += t - tq; tq = t; }
         // the quad's scores minus the reference first, the decision to move the reference next, the exponentials last: nothing
         // is ever exponentiated against a reference it exceeds by more than RESCALE_THR
         f32x4 av[4][RT], mx[RT];
@@ -275,16 +302,20 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
         for (int t = 0; t < RT; ++t) mx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (!TAIL || 4 * q + r < N) {
-                const f16x8 pk = pack_s<C, f16x8>(sa, r);
+            const f16x8 pk = pack_s<C, f16x8>(sa, r);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    av[r][t] = hw::mfma_f16(w.wl[t], pk, -m[t]);               // log2-domain score minus the reference
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) mx[t][k] = fmaxf(mx[t][k], av[r][t][k]);
-                }
-            }
+            for (int t = 0; t < RT; ++t) av[r][t] = hw::mfma_f16(w.wl[t], pk, -m[t]);      // log2-domain score minus the reference
         }
+        hw::sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (TAIL && 4 * q + r >= N) av[r][t][k] = -P_OFF;                     // keys beyond N: exp2 -> 0, never the maximum
+                    mx[t][k] = fmaxf(mx[t][k], av[r][t][k]);
+                }
         bool big = false;
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -303,18 +334,17 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
                 }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (!TAIL || 4 * q + r < N) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) l[t][k] += hw::exp2(av[r][t][k]);
-            }
-        }
+                for (int k = 0; k < 4; ++k) l[t][k] += hw::exp2(av[r][t][k]);
+        if (st) t_i += hw::clock() - tq;
     };
     const int nqf = N >> 2;                          // quads that lie entirely below N
     for (int q = 0; q < nqf; ++q) stats_quad(std::false_type{}, q);
     if (nqf < nq) stats_quad(std::true_type{}, nqf);
+    const unsigned long long t1 = st ? hw::clock() : 0, w1 = t_wait, s1 = t_s, i1 = t_i;
     f32x4 nlse[RT];                                  // minus the log2-domain log-sum-exp: initial accumulator of pass 2
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -327,58 +357,84 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
         }
 
     // ---- pass 2: P = exp2(A' - lse'), R = conv_w(P), 8 keys per 16-byte store ------------------------------------------------------
-    const int nblk = p.Np >> 3;
-    auto block = [&](auto tail_c, int kb) {
-        constexpr bool TAIL = decltype(tail_c)::value;
-        bf16x8 rp[RT][4];
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rp[t][k] = bf16x8{};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int u = 2 * kb + hf, j0 = 4 * u;
-            if (!TAIL || u < nq) {
-                if (u + 1 < nq) ks.advance(u + 1); else hw::dma_wait<0>();
-                f32x4 sa[NS];
-                bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
-                ks.done();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!TAIL || j0 + r < N) {
-                        const f16x8 pk = pack_s<C, f16x8>(sa, r);
-                        f32x4 pr[RT];
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            const f32x4 a = hw::mfma_f16(w.wl[t], pk, nlse[t]);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) pr[t][k] = hw::exp2(a[k]);
-                        }
-                        const f16x8 pp = pack_a<C, f16x8>(pr);
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                            const f32x4 rr = hw::mfma_f16(w.ww[t], pp, z);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) rp[t][k][4 * hf + r] = (bf16_t)rr[k];
-                        }
-                    }
-                }
-            }
-        }
+    // R leaves as 8-byte groups of 4 keys.  The stores of quad u are issued AFTER the LDS-DMA request made at the top of quad u + 1:
+    // vmcnt retires in issue order, so a store issued before a request would have to be acknowledged before that request's data
+    // counts as landed.  Addresses: one 32-bit lane offset on top of wave-uniform bases.
+    // quad-blocked layout [B, H, Np / 4, N, 4]: the 16 queries of the tile are contiguous (128 B) for a (head, quad)
+    char* const rbase = (char*)(p.R + (long)b * H * N * p.Np);
+    const unsigned rhead = (unsigned)(N * p.Np) * 2u;                       // bytes between heads
+    const unsigned rquad = (unsigned)N * 8u;                                // bytes between quads
+    const unsigned rlane = 4u * g4 * rhead + 8u * i;
+    bf16x4 rp[RT][4];
+    auto flush = [&](int u) {
         if (iok) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int g = 16 * t + 4 * g4 + k;
-                    if (g < H) *(bf16x8*)(p.R + (((long)b * H + g) * N + i) * p.Np + 8 * kb) = rp[t][k];
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (16 * t + 4 * g4 + k < H) *(bf16x4*)(rbase + (unsigned)(16 * t + k) * rhead + (unsigned)u * rquad + rlane) = rp[t][k];
         }
     };
-    const int nbf = N >> 3;                          // 8-key blocks that lie entirely below N
-    for (int kb = 0; kb < nbf; ++kb) block(std::false_type{}, kb);
-    if (nbf < nblk) block(std::true_type{}, nbf);
+    auto quad2 = [&](auto tail_c, int u) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const int j0 = 4 * u;
+        if (st) tq = hw::clock();
+        if (u + 1 < nq) ks.advance(u + 1); else hw::dma_wait<0>();
+        if (st) { const unsigned long long t = hw::clock(); t_wait += t - tq; tq = t; }
+        if (u > 0) flush(u - 1);
+        f32x4 sa[NS];
+        bd_scores<C>(ks.stage(0), zeros, lane, qf, sa);
+        ks.done();
+        if (st) { const unsigned long long t = hw::clock(); t_s += t - tq; tq = t; }
+        // stage-wise over the quad's four keys: 4 x RT independent MFMAs, then 4 x RT x 4 exponentials, ... (the chains of the four
+        // keys are independent: issued round-robin they hide each other's MFMA / transcendental latency)
+        f32x4 a[4][RT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f16x8 pk = pack_s<C, f16x8>(sa, r);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[r][t] = hw::mfma_f16(w.wl[t], pk, nlse[t]);
+        }
+        hw::sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(a[r][t][k]) : 0.f;
+        hw::sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f16x8 pp = pack_a<C, f16x8>(a[r]);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                a[r][t] = hw::mfma_f16(w.ww[t], pp, z);
+            }
+        }
+        hw::sched_fence();
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rp[t][k] = bf16x4{(bf16_t)a[0][t][k], (bf16_t)a[1][t][k], (bf16_t)a[2][t][k], (bf16_t)a[3][t][k]};
+        if (st) t_i += hw::clock() - tq;
+    };
+    for (int u = 0; u < nqf; ++u) quad2(std::false_type{}, u);
+    if (nqf < nq) quad2(std::true_type{}, nqf);
+    flush(nq - 1);
+    if (nq & 1) {                                    // Np is a multiple of 8: the pad columns of a half-filled last block are zero
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rp[t][k] = bf16x4{};
+        flush(nq);
+    }
+    if (st && lane == 0) {
+        unsigned long long* o = p.stamps + 12 * ((long)b * p.QT + it);
+        const unsigned long long t2 = hw::clock();
+        o[0] = t1 - t0; o[1] = w1; o[2] = s1; o[3] = i1;                          // pass 1: total, ring wait, scores, per-key stage
+        o[4] = t2 - t1; o[5] = t_wait - w1; o[6] = t_s - s1; o[7] = t_i - i1;      // pass 2
+    }
 }
 
 // the wave's zero block (read by the 48 lanes of a block-diagonal A operand that carry no row)
@@ -464,8 +520,7 @@ struct BwdAcc {
 
 // One (sample, 16-query tile).  pass A: delta_h = sum_j P_h dP_h (and dW_w); pass B: dA, dS (and dW_l).
 template <class C>
-DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<C>& w, BwdAcc<C>& acc, char* lds,
-                    const bf16_t* zero_page) {
+DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<C>& w, BwdAcc<C>& acc, char* lds) {
     constexpr int NS = C::NS, RT = C::RT, H = C::H, D = C::D;
     const int c = lane & 15, g4 = lane >> 4;
     const int N = p.N;
@@ -478,7 +533,7 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
     bf16x8 qf[NS][C::NC], dof[NS][C::NC];
     load_col_frags<C>(base, p.ld, i, iok, lane, qf);
     load_col_frags<C>(p.dO + (long)b * N * p.ldo, p.ldo, i, iok, lane, dof);
-    RowStream<C, 2> kv{{base + D, base + 2 * D}, p.ld, N, zero_page, lds + Ring<C>::ROWB, lane, 0};
+    RowStream<C, 2> kv{{base + D, base + 2 * D}, p.ld, N, lds + Ring<C>::ROWB, lane, 0};
     f32x4 nlse[RT], delta[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -492,40 +547,57 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
     const int nq = (N + 3) >> 2;
 
     // S, dR of a quad; P, dP per key of the quad
+    // dS leaves like R in the forward: 8-byte groups of 4 keys in the quad-blocked layout, issued after the next quad's requests
+    char* const sbase = (char*)(p.dS + (long)b * H * N * p.Np);
+    const unsigned shead = (unsigned)(N * p.Np) * 2u, squad = (unsigned)N * 8u;
+    const unsigned slane = 4u * g4 * shead + 8u * i;
+    bf16x4 sp[RT][4];
+    auto flush = [&](int u) {
+        if (iok) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (16 * t + 4 * g4 + k < H) *(bf16x4*)(sbase + (unsigned)(16 * t + k) * shead + (unsigned)u * squad + slane) = sp[t][k];
+        }
+    };
     // quads 0 .. nq - 1 twice (pass A, pass B), each requested one quad ahead
     kv.issue(0, 0);
     int seq = 0;
-    auto quad = [&](auto tail_c, int j0, f32x4 (&sa)[NS], f32x4 (&dra)[NS], f32x4 (&pr)[4][RT], f32x4 (&dp)[4][RT]) {
+    // S, dR of a quad; P, dP per key of the quad (stage-wise over the four keys, as the forward).  flush_u >= 0: the dS stores of
+    // that quad go out right behind this quad's requests.
+    auto quad = [&](auto tail_c, int j0, int flush_u, f32x4 (&sa)[NS], f32x4 (&dra)[NS], f32x4 (&pr)[4][RT], f32x4 (&dp)[4][RT]) {
         constexpr bool TAIL = decltype(tail_c)::value;
         ++seq;
         if (seq < 2 * nq) kv.advance(seq < nq ? seq : seq - nq); else hw::dma_wait<0>();
+        if (flush_u >= 0) flush(flush_u);
         bd_scores<C>(kv.stage(0), zeros, lane, qf, sa);
         bd_scores<C>(kv.stage(1), zeros, lane, dof, dra);
         kv.done();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (!TAIL || j0 + r < N) {
-                const f16x8 pk = pack_s<C, f16x8>(sa, r);
-                const bf16x8 dk = pack_s<C, bf16x8>(dra, r);
+            const f16x8 pk = pack_s<C, f16x8>(sa, r);
+            const bf16x8 dk = pack_s<C, bf16x8>(dra, r);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const f32x4 a = hw::mfma_f16(w.wl[t], pk, nlse[t]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pr[r][t][k] = hw::exp2(a[k]);
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < RT; ++t) { pr[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                pr[r][t] = hw::mfma_f16(w.wl[t], pk, nlse[t]);
+                dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);
             }
         }
+        hw::sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pr[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(pr[r][t][k]) : 0.f;     // keys beyond N: P = 0
     };
 
     // ---- pass A ---------------------------------------------------------------------------------------------------------------
     auto pass_a = [&](auto tail_c, int q) {
         f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
-        quad(tail_c, 4 * q, sa, dra, pr, dp);
+        quad(tail_c, 4 * q, -1, sa, dra, pr, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -544,64 +616,52 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
     if (nqf < nq) pass_a(std::true_type{}, nqf);
 
     // ---- pass B ---------------------------------------------------------------------------------------------------------------
-    const int nblk = p.Np >> 3;
-    auto pass_b = [&](auto tail_c, int kb) {
-        constexpr bool TAIL = decltype(tail_c)::value;
-        bf16x8 sp[RT][4];
+    auto pass_b = [&](auto tail_c, int u) {
+        f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
+        quad(tail_c, 4 * u, u - 1, sa, dra, pr, dp);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x8{};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int j0 = 8 * kb + 4 * hf;
-            if (!TAIL || 2 * kb + hf < nq) {
-                f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
-                quad(tail_c, j0, sa, dra, pr, dp);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA
-                    if (!TAIL || j0 + r < N) {
-                        const bf16x8 da = pack_a<C, bf16x8>(dp[r]);
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                            const f32x4 ds = hw::mfma_bf16(w.wlt[t], da, z);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) sp[t][k][4 * hf + r] = (bf16_t)ds[k];
-                        }
-                    }
-                }
-                // dW_l[g, h] += sum_e dA_g[e] S_h[e]   (S = scale * raw scores)
-                hw::lds_fence();
-                wg_store_a<C>(tx, lane, dp);
-                wg_store_s<C>(ty, lane, sa, p.scale);
-                hw::lds_fence();
-                wg_product<C>(tx, ty, lane, acc.wl);
-            }
-        }
-        if (iok) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int g = 16 * t + 4 * g4 + k;
-                    if (g < H) *(bf16x8*)(p.dS + (((long)b * H + g) * N + i) * p.Np + 8 * kb) = sp[t][k];
-                }
+                for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA (0 for keys beyond N: P = 0)
+        f32x4 ds[4][RT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bf16x8 da = pack_a<C, bf16x8>(dp[r]);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                ds[r][t] = hw::mfma_bf16(w.wlt[t], da, z);
+            }
         }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x4{(bf16_t)ds[0][t][k], (bf16_t)ds[1][t][k], (bf16_t)ds[2][t][k], (bf16_t)ds[3][t][k]};
+        // dW_l[g, h] += sum_e dA_g[e] S_h[e]   (S = scale * raw scores)
+        hw::lds_fence();
+        wg_store_a<C>(tx, lane, dp);
+        wg_store_s<C>(ty, lane, sa, p.scale);
+        hw::lds_fence();
+        wg_product<C>(tx, ty, lane, acc.wl);
     };
-    const int nbf = N >> 3;
-    for (int kb = 0; kb < nbf; ++kb) pass_b(std::false_type{}, kb);
-    if (nbf < nblk) pass_b(std::true_type{}, nbf);
+    for (int u = 0; u < nqf; ++u) pass_b(std::false_type{}, u);
+    if (nqf < nq) pass_b(std::true_type{}, nqf);
+    flush(nq - 1);
+    if (nq & 1) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x4{};
+        flush(nq);
+    }
 }
 
 // Persistent wave: items wave0, wave0 + nwaves, ...; at the end the workgroup's waves add their weight-gradient tiles through
 // LDS and the workgroup writes ONE partial [2][HP][HP] (summed by a second, tiny launch: no same-line atomics).
 template <class C>
-DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int lane, char* lds_all, const bf16_t* zero_page) {
+DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int lane, char* lds_all) {
     constexpr int RT = C::RT, HP = C::HP;
     constexpr int PER_WAVE = bwd_lds_per_wave<C>(), TILE_OFF = bwd_tile_off<C>();
     char* lds = lds_all + wave * PER_WAVE;
@@ -618,7 +678,7 @@ DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int 
     const int nitem = p.B * p.QT;
     for (int item = wg * nwave + wave; item < nitem; item += nwg * nwave) {
         const int b = item / p.QT, it = item - b * p.QT;
-        bwd_item<C>(p, b, it, lane, w, acc, lds, zero_page);
+        bwd_item<C>(p, b, it, lane, w, acc, lds);
     }
     // accumulator layout: row g = 16t + 4 g4 + r, column h = 16u + c
     hw::lds_fence();

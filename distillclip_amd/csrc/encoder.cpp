@@ -394,13 +394,13 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         } else {
             if (wl && mix_attn(p, N)) {
                 CK(dclip_attn_mix_fwd(s.qkv, 3 * D, wl, ww, s.Rm, s.stats, B, H, N, Np, hd, scale, st));
-                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, 1, st));
             } else if (wl && fused_student_attn(p, N)) {
                 CK(dclip_attn_student_fwd(s.qkv, 3 * D, wl, ww, s.S, s.P, s.Rm, s.ctx, D, B, H, N, Np, hd, scale, st));
             } else {
                 CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
                 CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
-                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, st));
+                CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, 0, st));
             }
         }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
@@ -510,7 +510,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), st));
         bf16_t* dctx = w.dh;
         CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, st));                         // dV = R^T dO
+        const int blk = (wl && mix_attn(p, N)) ? 1 : 0;        // R and dS of the register-resident score stage are quad-blocked
+        CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, blk, st));                    // dV = R^T dO
         if (wl && mix_attn(p, N)) {
             float* gl = GR(sr.cl) ? GR(sr.cl) : w.wg_dummy;
             float* gw = GR(sr.cw) ? GR(sr.cw) : w.wg_dummy + H * H;
@@ -520,8 +521,8 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
             CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
                                       wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
         }
-        CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, st));                      // dQ = dS K
-        CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, st));                      // dK = dS^T Q
+        CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dQ = dS K
+        CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dK = dS^T Q
         if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), st));
         if (r == 0 && params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), MR, 3 * D, st));
         CK(gemm(dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));

@@ -87,14 +87,30 @@ def attn_nt(a, lda, bm, ldb, B, H, N, hd, alpha=1.0, out_dtype=torch.float32):
     return c
 
 
-def attn_nn(a, bm, ldb, c, ldc, hd, alpha=1.0):
+def _score_dims(a):
+    """row-major [B,H,N,Np] or the quad-blocked [B,H,Np/4,N,4] of the register-resident score stage -> (B, H, N, Np, blocked)"""
+    if a.dim() == 5:
+        B, H, nq, N, four = a.shape
+        assert four == 4
+        return B, H, N, nq * 4, 1
     B, H, N, Np = a.shape
-    lib().dclip_attn_nn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, _stream())
+    return B, H, N, Np, 0
+
+
+def attn_nn(a, bm, ldb, c, ldc, hd, alpha=1.0):
+    B, H, N, Np, blocked = _score_dims(a)
+    lib().dclip_attn_nn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, blocked, _stream())
 
 
 def attn_tn(a, bm, ldb, c, ldc, hd, alpha=1.0):
-    B, H, N, Np = a.shape
-    lib().dclip_attn_tn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, _stream())
+    B, H, N, Np, blocked = _score_dims(a)
+    lib().dclip_attn_tn(_p(a), _p(bm), ldb, _p(c), ldc, B, H, N, Np, hd, alpha, blocked, _stream())
+
+
+def unblock_scores(a):
+    """quad-blocked [B,H,Np/4,N,4] -> row-major [B,H,N,Np] (tests / diagnostics)"""
+    B, H, nq, N, _ = a.shape
+    return a.permute(0, 1, 3, 2, 4).reshape(B, H, N, nq * 4)
 
 
 def attn_softmax_fwd(s, wl=None, ww=None, causal=False, save_p=False):
@@ -199,20 +215,21 @@ def attn_student_fwd(qkv, B, N, H, hd, wl, ww, scale, save=True):
 
 
 def attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale):
-    """register-resident head-mixed attention scores (include/dclip.h: dclip_attn_mix_fwd) -> (R bf16 [B,H,N,Np], lse f32 [B,H,N])"""
+    """register-resident head-mixed attention scores (include/dclip.h: dclip_attn_mix_fwd)
+    -> (R bf16, quad-blocked [B,H,Np/4,N,4] (unblock_scores() gives [B,H,N,Np]), lse f32 [B,H,N])"""
     _chk(qkv, wl, ww)
     Np = (N + 7) // 8 * 8
-    r = torch.full((B, H, N, Np), float('nan'), dtype=torch.bfloat16, device=qkv.device)    # the kernel writes every element
+    r = torch.full((B, H, Np // 4, N, 4), float('nan'), dtype=torch.bfloat16, device=qkv.device)    # the kernel writes every element
     stats = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     lib().dclip_attn_mix_fwd(_p(qkv), qkv.stride(0), _p(wl), _p(ww), _p(r), _p(stats), B, H, N, Np, hd, scale, _stream())
     return r, stats
 
 
 def attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, stats, scale, dwl, dww):
-    """-> dS bf16 [B,H,N,Np] (gradient of the scaled pre-mix scores); dwl / dww += (include/dclip.h: dclip_attn_mix_bwd)"""
+    """-> dS bf16, quad-blocked [B,H,Np/4,N,4] (gradient of the scaled pre-mix scores); dwl / dww += (include/dclip.h: dclip_attn_mix_bwd)"""
     _chk(qkv, d_ctx, wl, ww, stats, dwl, dww)
     Np = (N + 7) // 8 * 8
-    ds = torch.full((B, H, N, Np), float('nan'), dtype=torch.bfloat16, device=qkv.device)  # the kernel writes every element
+    ds = torch.full((B, H, Np // 4, N, 4), float('nan'), dtype=torch.bfloat16, device=qkv.device)  # the kernel writes every element
     ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(H), dtype=torch.uint8, device=qkv.device)
     lib().dclip_attn_mix_bwd(_p(qkv), qkv.stride(0), _p(d_ctx), d_ctx.stride(0), _p(wl), _p(ww), _p(stats), _p(ds), _p(dwl), _p(dww),
                              _p(ws), ws.numel(), B, H, N, Np, hd, scale, _stream())

@@ -100,10 +100,12 @@ int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x
  */
 int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B, int64_t H,
                   int64_t N, int64_t Np, int64_t hd, float alpha, void* stream);
+/* a_blocked != 0: A is in the quad-blocked layout the register-resident score stage writes (dclip_attn_mix_fwd / _bwd):
+ * [B, H, Np / 4, N, 4], element (i, j) of a (b, h) matrix at ((j >> 2) * N + i) * 4 + (j & 3); 0: row-major [B, H, N, Np]. */
 int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
-                  int64_t Np, int64_t hd, float alpha, void* stream);
+                  int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream);
 int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
-                  int64_t Np, int64_t hd, float alpha, void* stream);
+                  int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream);
 /* fused_fwd : ctx = softmax(scale * q k^T (+ causal mask)) v for plain multi-head attention (teacher, _common.py:73-89);
  *              qkv is the fused [B*N, 3*H*hd] projection ; scores / probabilities never reach HBM. */
 int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t hd,
@@ -130,9 +132,11 @@ int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const f
  * S = scale q k^T comes out of block-diagonal MFMAs with lane group g holding head 4s + g, so that the packed accumulator
  * registers are the B operand of A = conv_l(S) with the mix matrix as the A operand; P = softmax(A) is a per-register exp2
  * against the log-sum-exp that enters as the initial accumulator; R = conv_w(P) contracts over the accumulator's row index
- * (no lane movement).  Only R (bf16 [B,H,N,Np], pad columns zero) and the softmax statistics (f32 [B,H,N]: log-sum-exp of
- * every row of A) are stored.  The backward recomputes S, A, P from the packed qkv rows, forms dR = dO v^T on the fly and
- * writes dS (bf16, gradient of the scaled pre-mix scores); dWl / dWw += [H,H] leave as one partial tile per workgroup in
+ * (no lane movement).  Only R (bf16, quad-blocked [B,H,Np/4,N,4]: element (i, j) at ((j >> 2) * N + i) * 4 + (j & 3), pad
+ * columns zero -- a lane owns a query, so this is the layout in which a wave's 8-byte stores of 4 keys are contiguous over
+ * the 16 queries of a tile; dclip_attn_nn / _tn read it with a_blocked = 1) and the softmax statistics (f32 [B,H,N]:
+ * log-sum-exp of every row of A) are stored.  The backward recomputes S, A, P from the packed qkv rows, forms dR = dO v^T on the fly and
+ * writes dS (bf16, same quad-blocked layout, gradient of the scaled pre-mix scores); dWl / dWw += [H,H] leave as one partial tile per workgroup in
  * `workspace` (dclip_attn_mix_bwd_workspace_bytes(H) bytes, 16-byte aligned) summed by a second launch: no atomics, run-to-run
  * identical.  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
  *   forward   dclip_attn_mix_fwd -> dclip_attn_nn(R, v) ;   backward   dclip_attn_tn(R, dO) -> dV, dclip_attn_mix_bwd -> dS,
@@ -144,6 +148,7 @@ int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const f
  */
 int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd);
 size_t dclip_attn_mix_bwd_workspace_bytes(int64_t H);
+void dclip_attn_mix_debug_stamps(void* buf);   /* diagnostics: per-tile cycle counts of later dclip_attn_mix_fwd launches, NULL = off */
 int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* R, float* stats, int64_t B, int64_t H,
                        int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo, const float* Wl, const float* Ww,

@@ -224,7 +224,8 @@ def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
     wl = torch.eye(H, device='cuda') + _randn((H, H), 52, 0.15)
     ww = torch.eye(H, device='cuda') + _randn((H, H), 53, 0.15)
     scale = hd ** -0.5
-    R, lse = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)
+    Rb, lse = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)           # quad-blocked [B,H,Np/4,N,4]
+    R = ops.unblock_scores(Rb)
     q, k, v = (_heads(qkv[:, i * D:(i + 1) * D], B, N, H, hd) for i in range(3))
     sr = ((q @ k.transpose(-1, -2)) * scale).requires_grad_(True)
     wlr, wwr = wl.clone().requires_grad_(True), ww.clone().requires_grad_(True)
@@ -238,7 +239,8 @@ def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
     do = _heads(d_ctx, B, N, H, hd)
     rr.backward(do @ v.transpose(-1, -2))                               # dR = dO v^T
     dwl, dww = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
-    dS = ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww)
+    dSb = ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww)
+    dS = ops.unblock_scores(dSb)
     _close(dS[..., :N], sr.grad, 1e-2, 'dS')
     assert torch.count_nonzero(dS[..., N:]) == 0
     _close(dww, wwr.grad, 2e-2, 'dWw')                                  # bf16 operands of the weight-gradient MFMAs
@@ -256,11 +258,22 @@ def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
         _close(dwl, dwl3, 3e-2, 'dWl vs three kernels')
         _close(dww, dww3, 3e-2, 'dWw vs three kernels')
     # accumulation semantics of the weight gradients (+=) and run-to-run stability of the stored tensors
-    dS2 = ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww)
+    # the key / query products read the blocked layout directly: same ctx, dV, dQ, dK as from the row-major copies
+    for a_blk, a_row, bm, ldb, alpha in ((Rb, R, qkv[:, 2 * D:], 3 * D, 1.0), (dSb, dS, qkv[:, D:], 3 * D, scale)):
+        c1, c2 = (torch.zeros(B * N, D, dtype=torch.bfloat16, device='cuda') for _ in range(2))
+        ops.attn_nn(a_blk, bm, ldb, c1, D, hd, alpha)
+        ops.attn_nn(a_row.contiguous(), bm, ldb, c2, D, hd, alpha)
+        assert torch.equal(c1, c2)
+    for a_blk, a_row, bm, ldb, alpha in ((Rb, R, d_ctx, D, 1.0), (dSb, dS, qkv, 3 * D, scale)):
+        c1, c2 = (torch.zeros(B * N, D, dtype=torch.bfloat16, device='cuda') for _ in range(2))
+        ops.attn_tn(a_blk, bm, ldb, c1, D, hd, alpha)
+        ops.attn_tn(a_row.contiguous(), bm, ldb, c2, D, hd, alpha)
+        assert torch.equal(c1, c2)
+    dS2 = ops.unblock_scores(ops.attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, lse, scale, dwl, dww))
     assert torch.equal(dS2, dS)
     _close(dww, 2 * wwr.grad, 2e-2, 'dWw accumulates')
     R2, lse2 = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)
-    assert torch.equal(R2, R) and torch.equal(lse2, lse)
+    assert torch.equal(ops.unblock_scores(R2), R) and torch.equal(lse2, lse)
 
 
 def test_fused_student_attention_support_matrix():

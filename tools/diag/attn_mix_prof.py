@@ -18,7 +18,7 @@ for B, N, H, hd in shapes:
     wl = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).cuda()
     ww = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).cuda()
     scale = hd ** -0.5
-    R = torch.empty(B, H, N, Np, dtype=torch.bfloat16, device='cuda')
+    R = torch.empty(B, H, Np // 4, N, 4, dtype=torch.bfloat16, device='cuda')
     dS = torch.empty_like(R)
     lse = torch.empty(B, H, N, device='cuda')
     dwl, dww = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
@@ -26,6 +26,19 @@ for B, N, H, hd in shapes:
     fwd = lambda: lib().dclip_attn_mix_fwd(_p(qkv), 3 * D, _p(wl), _p(ww), _p(R), _p(lse), B, H, N, Np, hd, scale, _stream())
     bwd = lambda: lib().dclip_attn_mix_bwd(_p(qkv), 3 * D, _p(dctx), D, _p(wl), _p(ww), _p(lse), _p(dS), _p(dwl), _p(dww), _p(ws), ws.numel(),
                                            B, H, N, Np, hd, scale, _stream())
+    if os.environ.get('MIX_STAMPS') == '1':
+        QT = (N + 15) // 16
+        st = torch.zeros(B * QT, 12, dtype=torch.int64, device='cuda')
+        fwd(); torch.cuda.synchronize()
+        lib().dclip_attn_mix_debug_stamps(_p(st))
+        fwd(); torch.cuda.synchronize()
+        lib().dclip_attn_mix_debug_stamps(None)
+        med = st.double().median(0).values.tolist()
+        print('  fwd stamps (median cycles per tile): pass1 total %d wait %d scores %d stage %d | pass2 total %d wait %d scores %d stage %d' % tuple(med[:8]), flush=True)
+        rt = st[:, 10:12].double()
+        print('  prologue %d cycles, query fragments %d cycles; wave lifetime median %.1f us, first start -> last end %.1f us, start spread %.1f us'
+              % (med[8], med[9], (rt[:, 1] - rt[:, 0]).median().item() / 100, (rt[:, 1].max() - rt[:, 0].min()).item() / 100,
+                 (rt[:, 0].max() - rt[:, 0].min()).item() / 100), flush=True)
     for name, fn in (('fwd', fwd), ('bwd', bwd)):
         for _ in range(3):
             fn()

@@ -26,8 +26,6 @@ double rel_l2(const std::vector<double>& got, const std::vector<double>& ref) {
     return sqrt(d / (n > 0 ? n : 1));
 }
 
-alignas(16) static const unsigned short zero_page[1024] = {};
-
 template <int H, int HD>
 int run_case(int B, int N, uint64_t seed, double score_gain) {
     using C = amix::Cfg<H, HD>;
@@ -118,7 +116,7 @@ int run_case(int B, int N, uint64_t seed, double score_gain) {
     for (auto& x : Rk) x = (bf16_t)123.f;            // poison: every element up to Np must be written
     for (auto& x : dSk) x = (bf16_t)123.f;
     std::vector<float> stats((size_t)B * H * N, -7.f);
-    amix::FwdArgs fa{qkv.data(), ld, Wl.data(), Ww.data(), Rk.data(), stats.data(), B, N, Np, QT, scale};
+    amix::FwdArgs fa{qkv.data(), ld, Wl.data(), Ww.data(), Rk.data(), stats.data(), B, N, Np, QT, scale, nullptr};
     const int nitem = B * QT, nwgf = (nitem + 3) / 4;
     long ncoll = 0;
     {
@@ -135,7 +133,7 @@ int run_case(int B, int N, uint64_t seed, double score_gain) {
                     amix::zero_block_init<C>(mine, lane);
                     amix::FwdWeights<C> w;
                     amix::fwd_load_weights<C>(fa, lane, w);
-                    amix::fwd_item<C>(fa, item / QT, item % QT, lane, w, mine, (const bf16_t*)zero_page);
+                    amix::fwd_item<C>(fa, item / QT, item % QT, lane, w, mine);
                 });
             });
         for (auto& t : th) t.join();
@@ -151,7 +149,7 @@ int run_case(int B, int N, uint64_t seed, double score_gain) {
             th.emplace_back([&, wg] {
                 std::vector<char> lds(4 * amix::bwd_lds_per_wave<C>() + 16, (char)0x7f);
                 char* l16 = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-                emu::run_group(256, [&](int t) { amix::bwd_wave<C>(ba, wg, nwgb, t >> 6, 4, t & 63, l16, (const bf16_t*)zero_page); });
+                emu::run_group(256, [&](int t) { amix::bwd_wave<C>(ba, wg, nwgb, t >> 6, 4, t & 63, l16); });
             });
         for (auto& t : th) t.join();
     }
@@ -170,7 +168,7 @@ int run_case(int B, int N, uint64_t seed, double score_gain) {
         for (int h = 0; h < H; ++h)
             for (int i = 0; i < N; ++i) {
                 for (int j = 0; j < Np; ++j) {
-                    const size_t o = (((size_t)b * H + h) * N + i) * Np + j;
+                    const size_t o = ((((size_t)b * H + h) * (Np / 4) + (j >> 2)) * N + i) * 4 + (j & 3);      // quad-blocked layout
                     if (j < N) { gR[at(b, h, i, j)] = (double)(float)Rk[o]; gS[at(b, h, i, j)] = (double)(float)dSk[o]; }
                     else if ((float)Rk[o] != 0.f || (float)dSk[o] != 0.f) ++bad_pad;
                 }

@@ -215,6 +215,8 @@ static inline float log2(float x) { return log2f(x); }
 static inline bool any(bool p) { return emu::vote_any(p); }
 static inline void lds_fence() { emu::wave_sync(); }
 static inline void block_sync() { emu::block_sync(); }
+static inline void sched_fence() {}
+static inline unsigned long long clock() { return 0; }
 static inline void dma16(const void* src, char* dst) { emu::dma16(src, dst); }
 template <int N> static inline void dma_wait() { emu::dma_wait(N); }
 }  // namespace hw
