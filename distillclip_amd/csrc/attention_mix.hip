@@ -26,10 +26,30 @@ DEVFN f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f
 DEVFN float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 DEVFN float log2(float x) { return __builtin_amdgcn_logf(x); }
 DEVFN bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
-// LDS traffic of ONE wave (the weight-gradient tiles are wave-private): the LDS queue of a wave is in order, the fence keeps the
-// compiler from moving accesses across it
-DEVFN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// LDS traffic of ONE wave (the weight-gradient tiles are wave-private).  The DS queue of a wave is in order, so a ds_read issued
+// after a ds_write sees the data of every lane; all that is needed is that the compiler keeps the program order.  (A workgroup-
+// scope release fence would also emit s_waitcnt vmcnt(0): the full latency of the LDS-DMA request in flight for the next quad.)
+DEVFN void lds_fence() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 DEVFN void block_sync() { __syncthreads(); }
+// 16-byte LDS fragment read the compiler does not see as an LDS access (no s_waitcnt of its own: pair it with lds_wait_frags)
+template <int OFF>
+DEVFN bf16x8 lds_read_frag(const char* p) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(uintptr_t)p), "n"(OFF));
+    return v;
+}
+// at most N LDS operations issued after the reads of `f` are still outstanding -> `f` has landed (LDS returns in order); naming
+// the registers read-write keeps every consumer behind this statement
+template <int N, int GF>
+DEVFN void lds_wait_frags(bf16x8 (&f)[GF]) {
+    static_assert(GF == 4 || GF == 8, "fragment group of 4 or 8");
+    if constexpr (GF == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+}
+// the value lives in an AGPR from here on (MFMA B operands may be AGPRs; VGPRs stay free for what the VALU touches)
+DEVFN void pin_acc(bf16x8& v) { asm volatile("" : "+a"(v)); }
 DEVFN unsigned long long clock() { return __builtin_readcyclecounter(); }
 DEVFN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }    // no instruction moves across this point
 // LDS-DMA: 16 bytes per lane from the lane's own global address to (wave-uniform dst) + lane * 16; completion is tracked by vmcnt
@@ -43,6 +63,8 @@ template <int N> DEVFN void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n
 #include "attn_mix_wave.h"
 
 namespace {
+
+constexpr int BWD_MAX_WG = 256;
 
 // OCC = waves per SIMD the register allocation is held to (2: two workgroups per CU hide each other's latencies, at 256 registers)
 template <int H, int HD, int OCC>
@@ -67,29 +89,34 @@ __global__ __launch_bounds__(256, OCC) void attn_mix_fwd_kernel(amix::FwdArgs p)
     if (p.stamps && lane == 0) p.stamps[12 * (long)item + 11] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int H, int HD>
+template <int H, int HD, bool PASS_B>
 __global__ __launch_bounds__(256) void attn_mix_bwd_kernel(amix::BwdArgs p) {
     using C = amix::Cfg<H, HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    amix::bwd_wave<C>(p, blockIdx.x, gridDim.x, wave, 4, lane, smem);
+    amix::bwd_wave<C, PASS_B>(p, blockIdx.x, gridDim.x, wave, 4, lane, smem);
 }
 
-// dW[which][g, h] += mul * sum over the workgroups' partial tiles
-__global__ void attn_mix_wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int H, int HP, float* dWl, float* dWw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * H * H) return;
+// dW[which][g, h] += sum over the workgroups' partial tiles: one 256-thread block per output element, one partial per thread
+// (fixed summation order: run-to-run identical)
+__global__ __launch_bounds__(256) void attn_mix_wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int H, int HP, float* dWl, float* dWw) {
+    __shared__ float part[4];
+    const int idx = blockIdx.x;                       // (which, g, h)
     const int which = idx / (H * H), gh = idx - which * H * H, g = gh / H, h = gh - g * H;
-    const float* src = partial + (size_t)which * HP * HP + g * HP + h;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += src[(size_t)w * 2 * HP * HP];
-    float* dst = which == 0 ? dWl : dWw;
-    dst[gh] += s;
+    const int w = threadIdx.x;
+    float v = w < nwg ? partial[((size_t)w * 2 + which) * HP * HP + g * HP + h] : 0.f;
+    v = wave_sum(v);
+    if ((w & 63) == 0) part[w >> 6] = v;
+    __syncthreads();
+    if (w == 0) {
+        float* dst = which == 0 ? dWl : dWw;
+        dst[gh] += (part[0] + part[1]) + (part[2] + part[3]);
+    }
 }
 
-constexpr int BWD_MAX_WG = 256;
 unsigned long long* g_fwd_stamps = nullptr;      // diagnostics only (tools/diag/attn_mix_prof.py)
+unsigned long long* g_bwd_stamps[2] = {nullptr, nullptr};
 
 }  // namespace
 
@@ -115,11 +142,20 @@ extern "C" int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd) {
 
 // diagnostics: subsequent dclip_attn_mix_fwd launches of this process write 12 counts per (sample, 16-query tile) to `buf`
 // (u64 [B * ceil(N / 16)][12]: pass 1 total / ring wait / score MFMAs / per-key stage, then the same for pass 2); nullptr = off
-extern "C" void dclip_attn_mix_debug_stamps(void* buf) { g_fwd_stamps = (unsigned long long*)buf; }
+// bwd_a / bwd_b: u64 [B * ceil(N / 16)][8] for the two launches of dclip_attn_mix_bwd (total, ring wait, S + dR, per-key stage, dW product)
+extern "C" void dclip_attn_mix_debug_stamps(void* fwd, void* bwd_a, void* bwd_b) {
+    g_fwd_stamps = (unsigned long long*)fwd;
+    g_bwd_stamps[0] = (unsigned long long*)bwd_a;
+    g_bwd_stamps[1] = (unsigned long long*)bwd_b;
+}
 
-extern "C" size_t dclip_attn_mix_bwd_workspace_bytes(int64_t H) {
+static size_t partial_bytes(int64_t H) {
     const size_t HP = (size_t)((H + 15) / 16) * 16;
     return (size_t)BWD_MAX_WG * 2 * HP * HP * sizeof(float);
+}
+// per-workgroup weight-gradient partials [256][2][HP][HP] f32, then delta [B, H, N] f32
+extern "C" size_t dclip_attn_mix_bwd_workspace_bytes(int64_t B, int64_t H, int64_t N) {
+    return partial_bytes(H) + (((size_t)B * H * N * sizeof(float) + 255) & ~(size_t)255);
 }
 
 extern "C" int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* R, float* stats, int64_t B,
@@ -152,18 +188,24 @@ extern "C" int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, i
     DCLIP_REQUIRE(Np == ((N + 7) & ~(int64_t)7) && ld % 8 == 0 && ldo % 8 == 0 && ld >= 3 * H * hd && ldo >= H * hd && ((uintptr_t)qkv % 16) == 0 &&
                       ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dS % 16) == 0 && ((uintptr_t)workspace % 16) == 0,
                   "dclip_attn_mix_bwd: misaligned buffers");
-    DCLIP_REQUIRE(ws_bytes >= dclip_attn_mix_bwd_workspace_bytes(H), "dclip_attn_mix_bwd: workspace too small (%zu < %zu)", ws_bytes,
-                  dclip_attn_mix_bwd_workspace_bytes(H));
+    DCLIP_REQUIRE(ws_bytes >= dclip_attn_mix_bwd_workspace_bytes(B, H, N), "dclip_attn_mix_bwd: workspace too small (%zu < %zu)", ws_bytes,
+                  dclip_attn_mix_bwd_workspace_bytes(B, H, N));
     const int QT = (int)((N + 15) / 16);
     const int HP = (int)((H + 15) / 16) * 16;
     int blocks = (int)((B * QT + 3) / 4);
     if (blocks > BWD_MAX_WG) blocks = BWD_MAX_WG;        // persistent: one weight-gradient partial per workgroup
-    amix::BwdArgs p{(const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)ldo, Wl, Ww, stats, (bf16_t*)dS, (float*)workspace, (int)B, (int)N, (int)Np, QT, scale};
+    amix::BwdArgs p{(const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)ldo, Wl, Ww, stats, (bf16_t*)dS, (float*)workspace,
+                    (float*)((char*)workspace + partial_bytes(H)), (int)B, (int)N, (int)Np, QT, scale, g_bwd_stamps[0]};
     const double el = (double)B * H * N * Np;
     TraceScope tr(DCLIP_TRACE_ATTN, 8.0 * B * H * N * N * hd + 20.0 * el * H, 2.0 * el + 8.0 * B * N * H * hd, stream, (int)(B * H), (int)N, (int)hd, 8);
-    MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_bwd_kernel<HH, HD_>), dim3(blocks), dim3(256), (size_t)4 * amix::bwd_lds_per_wave<CC>(),
+    // pass A: delta = sum_j P dP, dW_w partials ; pass B: dS, dW_l partials
+    MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_bwd_kernel<HH, HD_, false>), dim3(blocks), dim3(256), (size_t)4 * amix::bwd_lds_per_wave<CC>(),
                                            (hipStream_t)stream, p));
-    hipLaunchKernelGGL(attn_mix_wgrad_reduce_kernel, dim3((unsigned)((2 * H * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    p.stamps = g_bwd_stamps[1];
+    MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_bwd_kernel<HH, HD_, true>), dim3(blocks), dim3(256), (size_t)4 * amix::bwd_lds_per_wave<CC>(),
+                                           (hipStream_t)stream, p));
+    static_assert(BWD_MAX_WG <= 256, "one partial per thread of the reduction block");
+    hipLaunchKernelGGL(attn_mix_wgrad_reduce_kernel, dim3((unsigned)(2 * H * H)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, blocks, (int)H, HP, dWl, dWw);
     return dclip_check_launch("dclip_attn_mix_bwd");
 }

@@ -67,8 +67,10 @@ struct BwdArgs {
     const float* stats;
     bf16_t* dS;                                  // gradient of the scaled pre-mix scores, quad-blocked like R, pad columns zero
     float* partial;                              // [workgroups][2][HP][HP] weight-gradient partial sums (dW_l, dW_w)
+    float* delta;                                // [B, H, N] sum_j P dP of every (head, query): pass A writes, pass B reads
     int B, N, Np, QT;
     float scale;
+    unsigned long long* stamps;                  // diagnostics (nullable): 8 cycle counts per (sample, tile), see bwd_item
 };
 
 // ---- weight operands -------------------------------------------------------------------------------------------------------
@@ -91,17 +93,28 @@ DEVFN T8 weight_frag(int lane, int t, F elem) {
 
 // ---- block-diagonal scores ---------------------------------------------------------------------------------------------------
 // Column-entity fragments (queries here): lane (c, g4) holds rows of head 4s + g4 of token `tok`, chunk ci.
-template <class C>
+// PIN: keep the fragments in the accumulator half of the register file (they are MFMA-only operands, which may be AGPRs): the
+// one-wave-per-SIMD backward kernels then keep their 256 VGPRs for what the VALU touches
+template <class C, bool PIN>
 DEVFN void load_col_frags(const bf16_t* mat, long ld, int tok, bool tok_ok, int lane, bf16x8 (&f)[C::NS][C::NC]) {
     const int g4 = lane >> 4;
+    // unconditional loads (clamped token / head) so that all of them are in flight together; lanes without a row are zeroed after
+    const bf16_t* row = mat + (long)(tok_ok ? tok : 0) * ld;
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
-        const bool ok = tok_ok && 4 * s + g4 < C::H;
-        const bf16_t* src = mat + (long)tok * ld + (4 * s + g4) * C::HD;
+        const bool head_ok = (C::H % 4 == 0) || 4 * s + g4 < C::H;
+        const bf16_t* src = row + (head_ok ? 4 * s + g4 : 0) * C::HD;
+#pragma unroll
+        for (int ci = 0; ci < C::NC; ++ci) f[s][ci] = *(const bf16x8*)(src + 8 * ci);
+    }
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        const bool ok = tok_ok && ((C::H % 4 == 0) || 4 * s + g4 < C::H);
 #pragma unroll
         for (int ci = 0; ci < C::NC; ++ci) {
-            bf16x8 z = {};
-            f[s][ci] = ok ? *(const bf16x8*)(src + 8 * ci) : z;
+            const bf16x8 z = {};
+            f[s][ci] = ok ? f[s][ci] : z;
+            if (PIN) hw::pin_acc(f[s][ci]);
         }
     }
 }
@@ -149,35 +162,52 @@ DEVFN void bd_scores(const char* stage, const char* zeros, int lane, const bf16x
     // MFMAs on the same accumulator are GS issues apart.  sched_fence() pins that order for the compiler.
     constexpr int GS = (8 / NC) < NS ? (8 / NC) : NS;          // sets per group
     constexpr int NG = (NS + GS - 1) / GS;
-    bf16x8 kf[2][GS][NC];
-    auto fetch = [&](int g, int buf) {
+    constexpr int GF = GS * NC;                                // fragments per group
+    bf16x8 kf[2][GF];
+    // NC lane addresses (chunk ci of the lane's row, swizzled), the set index is an immediate offset of the read.  The fragment
+    // reads are hidden from the compiler's LDS-DMA alias tracking (hw::lds_read_frag), which otherwise puts a vmcnt(0) -- the full
+    // latency of the request just made for the NEXT quad -- in front of them; hw::lds_wait_frags is the counted lgkmcnt wait that
+    // makes a group's registers valid (LDS returns in order: N later reads may stay outstanding)
+    const char* addr[NC];
 #pragma unroll
-        for (int u = 0; u < GS; ++u) {
-            const int s = g * GS + u;
-            if (s < NS) {
-                const bool head_ok = (C::H % 4 == 0) || 4 * s + g4 < C::H;
-                const char* ps = head_ok ? base : zeros;
+    for (int ci = 0; ci < NC; ++ci) addr[ci] = base + 16 * (ci ^ x);
+    auto fetch_set = [&](auto sc, int buf, int u) {           // set index as a type: it becomes the immediate offset of the reads
+        constexpr int sraw = decltype(sc)::value;
+        constexpr int s = sraw < NS ? sraw : 0;
+        const bool head_ok = sraw < NS && ((C::H % 4 == 0) || 4 * s + g4 < C::H);
 #pragma unroll
-                for (int ci = 0; ci < NC; ++ci) kf[buf][u][ci] = *(const bf16x8*)(ps + 16 * (4 * s * NC + (ci ^ x)));
-            }
+        for (int ci = 0; ci < NC; ++ci) {
+            if ((C::H % 4 == 0) && sraw < NS) kf[buf][u * NC + ci] = hw::lds_read_frag<64 * s * NC>(addr[ci]);
+            else kf[buf][u * NC + ci] = hw::lds_read_frag<0>(head_ok ? addr[ci] + 64 * s * NC : zeros);
         }
+    };
+    auto fetch = [&](auto gc, int buf) {
+        constexpr int g = decltype(gc)::value;
+        fetch_set(std::integral_constant<int, g * GS>{}, buf, 0);
+        if constexpr (GS > 1) fetch_set(std::integral_constant<int, g * GS + 1>{}, buf, 1);
+        static_assert(GS <= 2, "a group is one or two sets");
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(0, 0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
-        hw::sched_fence();
+    auto body = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < NG) { fetch(std::integral_constant<int, g + 1>{}, (g + 1) & 1); hw::lds_wait_frags<GF>(kf[g & 1]); }
+        else hw::lds_wait_frags<0>(kf[g & 1]);
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci)
 #pragma unroll
             for (int u = 0; u < GS; ++u) {
                 const int s = g * GS + u;
-                if (s < NS) acc[s] = hw::mfma_bf16(kf[g & 1][u][ci], colf[s][ci], acc[s]);
+                if (s < NS) acc[s] = hw::mfma_bf16(kf[g & 1][u * NC + ci], colf[s][ci], acc[s]);
             }
         hw::sched_fence();
-    }
+    };
+    fetch(std::integral_constant<int, 0>{}, 0);
+    body(std::integral_constant<int, 0>{});
+    if constexpr (NG > 1) body(std::integral_constant<int, 1>{});
+    if constexpr (NG > 2) body(std::integral_constant<int, 2>{});
+    if constexpr (NG > 3) body(std::integral_constant<int, 3>{});
+    static_assert(NG <= 4, "at most 4 fragment groups (NS <= 8)");
 }
 
 // NMAT row matrices walked quad by quad through a double-buffered ring: stage (2 m + parity) belongs to matrix m.
@@ -252,7 +282,7 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
     const bf16_t* base = p.qkv + (long)b * N * p.ld;
     const unsigned long long tq0 = p.stamps ? hw::clock() : 0;
     bf16x8 qf[NS][C::NC];
-    load_col_frags<C>(base, p.ld, i, iok, lane, qf);
+    load_col_frags<C, false>(base, p.ld, i, iok, lane, qf);
     const char* zeros = lds;
     RowStream<C, 1> ks{{base + D}, p.ld, N, lds + Ring<C>::ROWB, lane, 0};
     const int nq = (N + 3) >> 2;
@@ -460,7 +490,7 @@ struct BwdWeights {
     bf16x8 wlt[C::RT];    // dS_h = sum_g W_l[g, h] dA_g   : out = h, in = g, second-kind layout
 };
 
-template <class C>
+template <class C, bool PASS_B>
 DEVFN void bwd_load_weights(const BwdArgs& p, int lane, BwdWeights<C>& w) {
     const float* Wl = p.Wl; const float* Ww = p.Ww;
     const float sc = p.scale * LOG2E;
@@ -468,7 +498,7 @@ DEVFN void bwd_load_weights(const BwdArgs& p, int lane, BwdWeights<C>& w) {
     for (int t = 0; t < C::RT; ++t) {
         w.wl[t] = weight_frag<C, true, f16x8>(lane, t, [&](int g, int h) { return Wl[g * C::H + h] * sc; });
         w.wwt[t] = weight_frag<C, true, bf16x8>(lane, t, [&](int h, int g) { return Ww[g * C::H + h]; });
-        w.wlt[t] = weight_frag<C, false, bf16x8>(lane, t, [&](int h, int g) { return Wl[g * C::H + h]; });
+        if (PASS_B) w.wlt[t] = weight_frag<C, false, bf16x8>(lane, t, [&](int h, int g) { return Wl[g * C::H + h]; });
     }
 }
 
@@ -512,15 +542,12 @@ DEVFN void wg_product(const char* tx, const char* ty, int lane, f32x4 (&acc)[C::
     }
 }
 
-template <class C>
-struct BwdAcc {
-    f32x4 ww[C::RT][C::RT];     // dW_w[g, h] += sum dR_g P_h
-    f32x4 wl[C::RT][C::RT];     // dW_l[g, h] += sum dA_g S_h
-};
-
-// One (sample, 16-query tile).  pass A: delta_h = sum_j P_h dP_h (and dW_w); pass B: dA, dS (and dW_l).
-template <class C>
-DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<C>& w, BwdAcc<C>& acc, char* lds) {
+// One (sample, 16-query tile) of backward pass A (PASS_B = false): delta_h[i] = sum_j P_h dP_h -> p.delta, dW_w += dR P^T;
+// or of pass B (PASS_B = true): dA = P o (dP - delta), dS = conv_l^T(dA) -> p.dS, dW_l += dA S^T.  Two launches instead of two
+// passes of one kernel: each holds ONE weight-gradient accumulator and only its own mix operands next to the 2 x 96 fragment
+// registers of q and dO (one kernel with both spilled), and delta [B, H, N] f32 is a 2.4 MB round trip.
+template <class C, bool PASS_B>
+DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<C>& w, f32x4 (&acc)[C::RT][C::RT], char* lds) {
     constexpr int NS = C::NS, RT = C::RT, H = C::H, D = C::D;
     const int c = lane & 15, g4 = lane >> 4;
     const int N = p.N;
@@ -531,8 +558,8 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
     const char* zeros = lds;
     const bf16_t* base = p.qkv + (long)b * N * p.ld;
     bf16x8 qf[NS][C::NC], dof[NS][C::NC];
-    load_col_frags<C>(base, p.ld, i, iok, lane, qf);
-    load_col_frags<C>(p.dO + (long)b * N * p.ldo, p.ldo, i, iok, lane, dof);
+    load_col_frags<C, true>(base, p.ld, i, iok, lane, qf);
+    load_col_frags<C, true>(p.dO + (long)b * N * p.ldo, p.ldo, i, iok, lane, dof);
     RowStream<C, 2> kv{{base + D, base + 2 * D}, p.ld, N, lds + Ring<C>::ROWB, lane, 0};
     f32x4 nlse[RT], delta[RT];
 #pragma unroll
@@ -540,13 +567,13 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int g = 16 * t + 4 * g4 + k;
+            const bool ok = iok && g < H;
             // padded heads and queries beyond N: P = 0, so they drop out of every sum below
-            nlse[t][k] = (iok && g < H) ? -p.stats[((long)b * H + g) * N + i] * LOG2E : -P_OFF;
-            delta[t][k] = 0.f;
+            nlse[t][k] = ok ? -p.stats[((long)b * H + g) * N + i] * LOG2E : -P_OFF;
+            delta[t][k] = (PASS_B && ok) ? p.delta[((long)b * H + g) * N + i] : 0.f;
         }
-    const int nq = (N + 3) >> 2;
+    const int nq = (N + 3) >> 2, nqf = N >> 2;
 
-    // S, dR of a quad; P, dP per key of the quad
     // dS leaves like R in the forward: 8-byte groups of 4 keys in the quad-blocked layout, issued after the next quad's requests
     char* const sbase = (char*)(p.dS + (long)b * H * N * p.Np);
     const unsigned shead = (unsigned)(N * p.Np) * 2u, squad = (unsigned)N * 8u;
@@ -561,19 +588,26 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
                     if (16 * t + 4 * g4 + k < H) *(bf16x4*)(sbase + (unsigned)(16 * t + k) * shead + (unsigned)u * squad + slane) = sp[t][k];
         }
     };
-    // quads 0 .. nq - 1 twice (pass A, pass B), each requested one quad ahead
+
+    const bool st = p.stamps != nullptr;
+    unsigned long long t_wait = 0, t_s = 0, t_i = 0, t_w = 0, t0 = st ? hw::clock() : 0, tq = 0;
     kv.issue(0, 0);
-    int seq = 0;
-    // S, dR of a quad; P, dP per key of the quad (stage-wise over the four keys, as the forward).  flush_u >= 0: the dS stores of
-    // that quad go out right behind this quad's requests.
-    auto quad = [&](auto tail_c, int j0, int flush_u, f32x4 (&sa)[NS], f32x4 (&dra)[NS], f32x4 (&pr)[4][RT], f32x4 (&dp)[4][RT]) {
+    auto quad = [&](auto tail_c, int u) {
         constexpr bool TAIL = decltype(tail_c)::value;
-        ++seq;
-        if (seq < 2 * nq) kv.advance(seq < nq ? seq : seq - nq); else hw::dma_wait<0>();
-        if (flush_u >= 0) flush(flush_u);
-        bd_scores<C>(kv.stage(0), zeros, lane, qf, sa);
-        bd_scores<C>(kv.stage(1), zeros, lane, dof, dra);
+        const int j0 = 4 * u;
+        if (st) tq = hw::clock();
+        if (u + 1 < nq) kv.advance(u + 1); else hw::dma_wait<0>();
+        if (st) { const unsigned long long t = hw::clock(); t_wait += t - tq; tq = t; }
+        if (PASS_B && u > 0) flush(u - 1);
+        // the weight-gradient product of the PREVIOUS quad: its tiles were written at the end of that iteration, so neither the
+        // LDS write latency nor the read latency sits on this iteration's critical path
+        if (u > 0) wg_product<C>(tx, ty, lane, acc);
+        f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
+        bd_scores<C>(kv.stage(0), zeros, lane, qf, sa);        // S  = q k^T (raw)
+        bd_scores<C>(kv.stage(1), zeros, lane, dof, dra);      // dR = dO v^T
         kv.done();
+        if (st) { const unsigned long long t = hw::clock(); t_s += t - tq; tq = t; }
+        // stage-wise over the quad's four keys, as the forward
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const f16x8 pk = pack_s<C, f16x8>(sa, r);
@@ -582,7 +616,7 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             for (int t = 0; t < RT; ++t) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 pr[r][t] = hw::mfma_f16(w.wl[t], pk, nlse[t]);
-                dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);
+                dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);     // dP = conv_w^T(dR)
             }
         }
         hw::sched_fence();
@@ -592,75 +626,85 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pr[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(pr[r][t][k]) : 0.f;     // keys beyond N: P = 0
-    };
-
-    // ---- pass A ---------------------------------------------------------------------------------------------------------------
-    auto pass_a = [&](auto tail_c, int q) {
-        f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
-        quad(tail_c, 4 * q, -1, sa, dra, pr, dp);
+        if (!PASS_B) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) delta[t][k] += pr[r][t][k] * dp[r][t][k];
-        // dW_w[g, h] += sum_e dR_g[e] P_h[e]
-        hw::lds_fence();
-        wg_store_s<C>(tx, lane, dra, 1.f);
-        wg_store_a<C>(ty, lane, pr);
-        hw::lds_fence();
-        wg_product<C>(tx, ty, lane, acc.ww);
-    };
-    const int nqf = N >> 2;
-    for (int q = 0; q < nqf; ++q) pass_a(std::false_type{}, q);
-    if (nqf < nq) pass_a(std::true_type{}, nqf);
-
-    // ---- pass B ---------------------------------------------------------------------------------------------------------------
-    auto pass_b = [&](auto tail_c, int u) {
-        f32x4 sa[NS], dra[NS], pr[4][RT], dp[4][RT];
-        quad(tail_c, 4 * u, u - 1, sa, dra, pr, dp);
+                    for (int k = 0; k < 4; ++k) delta[t][k] += pr[r][t][k] * dp[r][t][k];
+            if (st) { const unsigned long long t = hw::clock(); t_i += t - tq; tq = t; }
+            // dW_w[g, h] += sum_e dR_g[e] P_h[e]: operands to the tiles now, product at the top of the next iteration
+            hw::lds_fence();
+            wg_store_s<C>(tx, lane, dra, 1.f);
+            wg_store_a<C>(ty, lane, pr);
+            hw::lds_fence();
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA (0 for keys beyond N: P = 0)
-        f32x4 ds[4][RT];
+                    for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA
+            hw::sched_fence();
+            // dS = conv_l^T(dA), two keys at a time (their packed pair is half of the 8-byte store)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bf16x8 da = pack_a<C, bf16x8>(dp[r]);
+            for (int r2 = 0; r2 < 4; r2 += 2) {
+                f32x4 ds[2][RT];
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                ds[r][t] = hw::mfma_bf16(w.wlt[t], da, z);
+                for (int e = 0; e < 2; ++e) {
+                    const bf16x8 da = pack_a<C, bf16x8>(dp[r2 + e]);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        ds[e][t] = hw::mfma_bf16(w.wlt[t], da, z);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sp[t][k][r2] = (bf16_t)ds[0][t][k]; sp[t][k][r2 + 1] = (bf16_t)ds[1][t][k]; }
             }
+            if (st) { const unsigned long long t = hw::clock(); t_i += t - tq; tq = t; }
+            // dW_l[g, h] += sum_e dA_g[e] S_h[e]   (S = scale * raw scores): product at the top of the next iteration
+            hw::lds_fence();
+            wg_store_a<C>(tx, lane, dp);
+            wg_store_s<C>(ty, lane, sa, p.scale);
+            hw::lds_fence();
         }
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x4{(bf16_t)ds[0][t][k], (bf16_t)ds[1][t][k], (bf16_t)ds[2][t][k], (bf16_t)ds[3][t][k]};
-        // dW_l[g, h] += sum_e dA_g[e] S_h[e]   (S = scale * raw scores)
-        hw::lds_fence();
-        wg_store_a<C>(tx, lane, dp);
-        wg_store_s<C>(ty, lane, sa, p.scale);
-        hw::lds_fence();
-        wg_product<C>(tx, ty, lane, acc.wl);
+        if (st) t_w += hw::clock() - tq;
     };
-    for (int u = 0; u < nqf; ++u) pass_b(std::false_type{}, u);
-    if (nqf < nq) pass_b(std::true_type{}, nqf);
-    flush(nq - 1);
-    if (nq & 1) {
+    for (int u = 0; u < nqf; ++u) quad(std::false_type{}, u);
+    if (nqf < nq) quad(std::true_type{}, nqf);
+    wg_product<C>(tx, ty, lane, acc);                  // the last quad's
+    if (PASS_B) {
+        flush(nq - 1);
+        if (nq & 1) {                                // Np is a multiple of 8: the pad columns of a half-filled last block are zero
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sp[t][k] = bf16x4{};
+            flush(nq);
+        }
+    } else {
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sp[t][k] = bf16x4{};
-        flush(nq);
+            for (int k = 0; k < 4; ++k) {
+                const int g = 16 * t + 4 * g4 + k;
+                if (iok && g < H) p.delta[((long)b * H + g) * N + i] = delta[t][k];
+            }
+    }
+    if (st && lane == 0) {
+        unsigned long long* o = p.stamps + 8 * ((long)b * p.QT + it);
+        o[0] = hw::clock() - t0; o[1] = t_wait; o[2] = t_s; o[3] = t_i; o[4] = t_w;     // total, ring wait, S + dR, per-key stage, dW product
     }
 }
 
 // Persistent wave: items wave0, wave0 + nwaves, ...; at the end the workgroup's waves add their weight-gradient tiles through
-// LDS and the workgroup writes ONE partial [2][HP][HP] (summed by a second, tiny launch: no same-line atomics).
-template <class C>
+// LDS and the workgroup writes ONE partial [HP][HP] into slot `PASS_B ? 0 : 1` of its [2][HP][HP] record (summed by a tiny
+// launch afterwards: no same-line atomics, run-to-run identical).
+template <class C, bool PASS_B>
 DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int lane, char* lds_all) {
     constexpr int RT = C::RT, HP = C::HP;
     constexpr int PER_WAVE = bwd_lds_per_wave<C>(), TILE_OFF = bwd_tile_off<C>();
@@ -669,34 +713,30 @@ DEVFN void bwd_wave(const BwdArgs& p, int wg, int nwg, int wave, int nwave, int 
     for (int o = lane * 16; o < 2 * WG_TILE; o += 64 * 16) *(u32x4*)(lds + TILE_OFF + o) = u32x4{0u, 0u, 0u, 0u};
     zero_block_init<C>(lds, lane);
     BwdWeights<C> w;
-    bwd_load_weights<C>(p, lane, w);
-    BwdAcc<C> acc;
+    bwd_load_weights<C, PASS_B>(p, lane, w);
+    f32x4 acc[RT][RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int u = 0; u < RT; ++u) { acc.ww[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.wl[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int u = 0; u < RT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nitem = p.B * p.QT;
     for (int item = wg * nwave + wave; item < nitem; item += nwg * nwave) {
         const int b = item / p.QT, it = item - b * p.QT;
-        bwd_item<C>(p, b, it, lane, w, acc, lds);
+        bwd_item<C, PASS_B>(p, b, it, lane, w, acc, lds);
     }
     // accumulator layout: row g = 16t + 4 g4 + r, column h = 16u + c
     hw::lds_fence();
-    float* mine = (float*)(lds + TILE_OFF);          // [2][HP][HP] f32 = 8 KiB at HP = 32
+    float* mine = (float*)(lds + TILE_OFF);          // [HP][HP] f32
     const int c = lane & 15, g4 = lane >> 4;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int u = 0; u < RT; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int g = 16 * t + 4 * g4 + r, h = 16 * u + c;
-                mine[g * HP + h] = acc.wl[t][u][r];
-                mine[HP * HP + g * HP + h] = acc.ww[t][u][r];
-            }
+            for (int r = 0; r < 4; ++r) mine[(16 * t + 4 * g4 + r) * HP + 16 * u + c] = acc[t][u][r];
     hw::block_sync();
-    float* out = p.partial + (long)wg * 2 * HP * HP;
-    for (int idx = wave * 64 + lane; idx < 2 * HP * HP; idx += nwave * 64) {
+    float* out = p.partial + ((long)wg * 2 + (PASS_B ? 0 : 1)) * HP * HP;
+    for (int idx = wave * 64 + lane; idx < HP * HP; idx += nwave * 64) {
         float s = 0.f;
         for (int v = 0; v < nwave; ++v) s += ((const float*)(lds_all + v * PER_WAVE + TILE_OFF))[idx];
         out[idx] = s;

@@ -200,7 +200,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         w.dR = b.take<bf16_t>(SN); w.dS = b.take<bf16_t>(SN); w.dout = b.take<bf16_t>(B * p.E);
         w.tok_sum = b.take<float>((int64_t)N * D);
         w.wg_dummy = b.take<float>(2 * p.H * p.H);
-        w.mix_ws_bytes = p.c.head_mix ? dclip_attn_mix_bwd_workspace_bytes(p.H) : 0;
+        w.mix_ws_bytes = p.c.head_mix ? dclip_attn_mix_bwd_workspace_bytes(B, p.H, N) : 0;
         w.mix_ws = w.mix_ws_bytes ? (float*)b.take<char>(w.mix_ws_bytes) : nullptr;
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {

@@ -230,7 +230,7 @@ def attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, stats, scale, dwl, dww):
     _chk(qkv, d_ctx, wl, ww, stats, dwl, dww)
     Np = (N + 7) // 8 * 8
     ds = torch.full((B, H, Np // 4, N, 4), float('nan'), dtype=torch.bfloat16, device=qkv.device)  # the kernel writes every element
-    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(H), dtype=torch.uint8, device=qkv.device)
+    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device=qkv.device)
     lib().dclip_attn_mix_bwd(_p(qkv), qkv.stride(0), _p(d_ctx), d_ctx.stride(0), _p(wl), _p(ww), _p(stats), _p(ds), _p(dwl), _p(dww),
                              _p(ws), ws.numel(), B, H, N, Np, hd, scale, _stream())
     return ds

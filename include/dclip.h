@@ -137,8 +137,8 @@ int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const f
  * the 16 queries of a tile; dclip_attn_nn / _tn read it with a_blocked = 1) and the softmax statistics (f32 [B,H,N]:
  * log-sum-exp of every row of A) are stored.  The backward recomputes S, A, P from the packed qkv rows, forms dR = dO v^T on the fly and
  * writes dS (bf16, same quad-blocked layout, gradient of the scaled pre-mix scores); dWl / dWw += [H,H] leave as one partial tile per workgroup in
- * `workspace` (dclip_attn_mix_bwd_workspace_bytes(H) bytes, 16-byte aligned) summed by a second launch: no atomics, run-to-run
- * identical.  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
+ * `workspace` (dclip_attn_mix_bwd_workspace_bytes(B, H, N) bytes, 16-byte aligned; it also carries the [B,H,N] softmax-backward
+ * row sums between the two launches of the backward) summed by a further launch: no atomics, run-to-run identical.  The products over keys / queries stay with dclip_attn_nn / dclip_attn_tn:
  *   forward   dclip_attn_mix_fwd -> dclip_attn_nn(R, v) ;   backward   dclip_attn_tn(R, dO) -> dV, dclip_attn_mix_bwd -> dS,
  *             dclip_attn_nn(dS, k) -> dQ, dclip_attn_tn(dS, q) -> dK.
  * Replaces dclip_attn_nt + dclip_attn_softmax_fwd and dclip_attn_nt + dclip_attn_softmax_bwd (S f32, P, dR never stored).
@@ -147,8 +147,8 @@ int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const f
  * unfused kernels).
  */
 int dclip_attn_mix_supported(int64_t H, int64_t N, int64_t hd);
-size_t dclip_attn_mix_bwd_workspace_bytes(int64_t H);
-void dclip_attn_mix_debug_stamps(void* buf);   /* diagnostics: per-tile cycle counts of later dclip_attn_mix_fwd launches, NULL = off */
+size_t dclip_attn_mix_bwd_workspace_bytes(int64_t B, int64_t H, int64_t N);
+void dclip_attn_mix_debug_stamps(void* fwd, void* bwd_a, void* bwd_b);   /* diagnostics: per-tile cycle counts of later launches, NULL = off */
 int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* R, float* stats, int64_t B, int64_t H,
                        int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
 int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo, const float* Wl, const float* Ww,

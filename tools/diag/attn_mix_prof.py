@@ -22,7 +22,7 @@ for B, N, H, hd in shapes:
     dS = torch.empty_like(R)
     lse = torch.empty(B, H, N, device='cuda')
     dwl, dww = torch.zeros(H, H, device='cuda'), torch.zeros(H, H, device='cuda')
-    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(H), dtype=torch.uint8, device='cuda')
+    ws = torch.empty(lib().dclip_attn_mix_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device='cuda')
     fwd = lambda: lib().dclip_attn_mix_fwd(_p(qkv), 3 * D, _p(wl), _p(ww), _p(R), _p(lse), B, H, N, Np, hd, scale, _stream())
     bwd = lambda: lib().dclip_attn_mix_bwd(_p(qkv), 3 * D, _p(dctx), D, _p(wl), _p(ww), _p(lse), _p(dS), _p(dwl), _p(dww), _p(ws), ws.numel(),
                                            B, H, N, Np, hd, scale, _stream())
@@ -30,9 +30,14 @@ for B, N, H, hd in shapes:
         QT = (N + 15) // 16
         st = torch.zeros(B * QT, 12, dtype=torch.int64, device='cuda')
         fwd(); torch.cuda.synchronize()
-        lib().dclip_attn_mix_debug_stamps(_p(st))
-        fwd(); torch.cuda.synchronize()
-        lib().dclip_attn_mix_debug_stamps(None)
+        sa, sb = torch.zeros(B * QT, 8, dtype=torch.int64, device='cuda'), torch.zeros(B * QT, 8, dtype=torch.int64, device='cuda')
+        bwd(); torch.cuda.synchronize()
+        lib().dclip_attn_mix_debug_stamps(_p(st), _p(sa), _p(sb))
+        fwd(); bwd(); torch.cuda.synchronize()
+        lib().dclip_attn_mix_debug_stamps(None, None, None)
+        for nm, t in (('bwd pass A', sa), ('bwd pass B', sb)):
+            print('  %s stamps (median cycles per tile): total %d ring wait %d S+dR %d per-key stage %d dW product %d' %
+                  ((nm,) + tuple(t.double().median(0).values.tolist()[:5])), flush=True)
         med = st.double().median(0).values.tolist()
         print('  fwd stamps (median cycles per tile): pass1 total %d wait %d scores %d stage %d | pass2 total %d wait %d scores %d stage %d' % tuple(med[:8]), flush=True)
         rt = st[:, 10:12].double()

@@ -142,14 +142,16 @@ int run_case(int B, int N, uint64_t seed, double score_gain) {
     // ---- emulated backward (persistent workgroups + the partial-sum reduction) ----------------------------------------------------
     const int nwgb = nitem >= 12 ? 3 : 1;
     std::vector<float> partial((size_t)nwgb * 2 * HP * HP, -1.f);
-    amix::BwdArgs ba{qkv.data(), ld, dO.data(), (long)D, Wl.data(), Ww.data(), stats.data(), dSk.data(), partial.data(), B, N, Np, QT, scale};
-    {
+    std::vector<float> delta((size_t)B * H * N, 77.f);
+    amix::BwdArgs ba{qkv.data(), ld, dO.data(), (long)D, Wl.data(), Ww.data(), stats.data(), dSk.data(), partial.data(), delta.data(), B, N, Np, QT, scale, nullptr};
+    for (int pass = 0; pass < 2; ++pass) {           // two launches: pass A (delta, dW_w), then pass B (dS, dW_l)
         std::vector<std::thread> th;
         for (int wg = 0; wg < nwgb; ++wg)
             th.emplace_back([&, wg] {
                 std::vector<char> lds(4 * amix::bwd_lds_per_wave<C>() + 16, (char)0x7f);
                 char* l16 = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-                emu::run_group(256, [&](int t) { amix::bwd_wave<C>(ba, wg, nwgb, t >> 6, 4, t & 63, l16); });
+                if (pass == 0) emu::run_group(256, [&](int t) { amix::bwd_wave<C, false>(ba, wg, nwgb, t >> 6, 4, t & 63, l16); });
+                else emu::run_group(256, [&](int t) { amix::bwd_wave<C, true>(ba, wg, nwgb, t >> 6, 4, t & 63, l16); });
             });
         for (auto& t : th) t.join();
     }
