@@ -49,7 +49,17 @@ def checkpoint_dict(model, optimizer=None, scheduler=None, epoch=0, global_step=
 
 
 def save_checkpoint(path, model, optimizer=None, scheduler=None, epoch=0, global_step=0):
-    torch.save(checkpoint_dict(model, optimizer, scheduler, epoch, global_step), path)
+    """Data-parallel runs: call on EVERY rank.  With the sharded optimizer each rank holds 1/W of the Adam moments, so building
+    the dict is a collective (FusedAdamW.state_dict all-gathers them); only rank 0 writes the file, and all ranks leave
+    together.  (Lightning's rank-0-only ModelCheckpoint convention would dead-lock in that all-gather: keep the call
+    collective, or run DCLIP_DP_MODE=allreduce, where every rank holds the full state and rank 0 may save alone.)"""
+    import torch.distributed as dist
+    ckpt = checkpoint_dict(model, optimizer, scheduler, epoch, global_step)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi or dist.get_rank() == 0:
+        torch.save(ckpt, path)
+    if multi:
+        dist.barrier()
 
 
 def load_checkpoint(path, model, optimizer=None, scheduler=None, strict=True):

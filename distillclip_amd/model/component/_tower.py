@@ -294,7 +294,7 @@ class HipTower:
         # data-parallel run: every gradient bucket is handed to the exchange as soon as its last writer is enqueued, so the
         # reduce-scatter of block l travels under the backward GEMMs of block l - 1
         cb, failed = None, []
-        if self.dp is not None and self.sync is not None and self.sync.enabled:
+        if self.dp is not None and self.sync is not None and self.sync.enabled and self.sync.armed:
             def _ready(_user, bucket):
                 try:
                     self.sync.bucket_ready(self, bucket)

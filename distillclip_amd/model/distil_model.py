@@ -81,7 +81,11 @@ class DistillModel(nn.Module):
         bucketed reduce-scatter released from inside the backward + sharded AdamW + parameter all-gather (parallel.py)."""
         sync = self._ensure_sync()
         if loss is not None:
-            loss.backward()
+            sync.armed = sync.enabled                          # per-bucket release from inside the tower's backward: only here
+            try:
+                loss.backward()
+            finally:
+                sync.armed = False
         if not sync.enabled:
             return
         tw = self.student._tower

@@ -171,7 +171,11 @@ class DualDistillModel(nn.Module):
         each tower's flat buffer is all-reduced on a side stream right after its backward has been enqueued."""
         sync = self._ensure_sync()
         if loss is not None:                                   # None: the caller already ran loss.backward()
-            loss.backward()
+            sync.armed = sync.enabled                          # per-bucket release from inside the towers' backward: only here
+            try:
+                loss.backward()
+            finally:
+                sync.armed = False
         if not sync.enabled:
             return
         for tw in self.towers():

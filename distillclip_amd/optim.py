@@ -69,7 +69,13 @@ class FusedAdamW:
     def _moments(self, tw):
         key = id(tw)
         n = tw.dp.shard_elems if self._sharded(tw) else tw.flat.numel()
-        if key not in self._state or self._state[key][0].numel() != max(n, 1):
+        if key in self._state and self._state[key][0].numel() != max(n, 1):
+            # the layout of the moments changed under us (torch.distributed initialised, or the shard plan swapped, after state
+            # was created or loaded): re-zeroing would silently drop trained / restored Adam moments
+            raise RuntimeError(f'FusedAdamW: optimizer state of {self._state[key][0].numel()} elements, but the tower now needs '
+                               f'{max(n, 1)} (sharded={self._sharded(tw)}): build the optimizer / load its state after '
+                               'torch.distributed and the data-parallel plan are set up')
+        if key not in self._state:
             self._state[key] = (torch.zeros(max(n, 1), dtype=torch.float32, device=tw.flat.device),
                                 torch.zeros(max(n, 1), dtype=torch.float32, device=tw.flat.device))
         return self._state[key]
@@ -102,6 +108,7 @@ class FusedAdamW:
                     w.wait()
         tw.wcache_dirty = True
         tw.grads_ready = None
+        tw.dp_unstepped.clear()                     # the exchanged averages are consumed: the next backward may release again
         if s is not None:
             tw.opt_done = torch.cuda.Event()
             tw.opt_done.record(s)
@@ -203,7 +210,10 @@ class FusedAdamW:
 
     def state_dict(self, params=None):
         """`params`: the iteration order torch.optim.AdamW would have been built with (reference distil_model.py:161,
-        dual_distill_model.py:195: filter(requires_grad, self.parameters())); default = canonical tower order."""
+        dual_distill_model.py:195: filter(requires_grad, self.parameters())); default = canonical tower order.
+
+        COLLECTIVE in a sharded data-parallel run: every rank holds 1/W of m / v, so every rank must call this (the moments are
+        all-gathered per bucket); checkpoint.save_checkpoint does that and lets rank 0 alone write the file."""
         self.join()
         slots = self._slots(params)
         state = {}

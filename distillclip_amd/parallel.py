@@ -93,13 +93,20 @@ class GradSync:
     released from inside the backward + sharded optimizer + parameter all-gather; otherwise the flat all-reduce of round 1."""
 
     def __init__(self, bucket_elems=32 * 1024 * 1024, sharded=None):
-        self.enabled = _dist_on() and dist.get_world_size() > 1
+        mode = os.environ.get('DCLIP_DP_MODE', 'reduce_scatter')
+        # DCLIP_DP_MODE=off: somebody else owns the gradient exchange (Lightning's DDP wrapper over p.grad, a torch optimizer):
+        # nothing here touches the gradients
+        self.enabled = mode != 'off' and _dist_on() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if _dist_on() else 1
         self.rank = dist.get_rank() if _dist_on() else 0
         self.bucket = bucket_elems
         if sharded is None:
-            sharded = os.environ.get('DCLIP_DP_MODE', 'reduce_scatter') != 'allreduce'
+            sharded = mode != 'allreduce'
         self.sharded = bool(sharded) and 64 % max(self.world, 1) == 0      # parameter segments are 64-element aligned
+        # The per-bucket release from INSIDE a tower's backward (reduce-scatter + clearing of the exchanged bucket) happens only
+        # while armed, i.e. inside backward_and_sync(): a bare loss.backward() leaves p.grad whole for whoever consumes it
+        # (gradient clipping, grad-norm logging, a DDP wrapper, a torch optimizer).
+        self.armed = False
         self._stream = None
         self._pending = []
 
@@ -145,6 +152,7 @@ class GradSync:
         tw.dp = sh
         tw.gshard = torch.zeros(max(sh.shard_elems, 1), dtype=torch.float32, device=tw.flat.device)
         tw.dp_released = 0
+        tw.dp_unstepped = set()
         return sh
 
     def bucket_ready(self, tw, i, after=None):
@@ -156,6 +164,12 @@ class GradSync:
         tw.dp_released = max(tw.dp_released, i + 1)
         if b is None:
             return
+        if i in tw.dp_unstepped:
+            # the shard holds an average the optimizer has not consumed yet: a second backward before step() (gradient
+            # accumulation) would silently replace it
+            raise RuntimeError('GradSync: gradient bucket released twice before optimizer.step(): the sharded exchange supports '
+                               'accumulate_grad_batches = 1 only (use DCLIP_DP_MODE=allreduce to accumulate)')
+        tw.dp_unstepped.add(i)
         b0, b1, o0, o1, off, _ = b
         g = tw.flat_grad
         s = self.stream_for(g)

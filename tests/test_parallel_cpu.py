@@ -230,6 +230,26 @@ def _sharded_worker(rank, world, rdzv, q):
         opt.step()
     sd = opt.state_dict()                                              # collective: gathers the ranks' m / v shards
     assert tw.dp.shard_elems * world == sum(b1 - b0 for (b0, b1), b in zip(_BUCKETS, tw.dp.buckets) if b is not None)
+    # a second backward before step() (gradient accumulation) would replace the un-consumed shard average: refused
+    tw.flat_grad.add_(1.0)
+    sync.bucket_ready(tw, 0)
+    try:
+        sync.bucket_ready(tw, 0)
+        twice = 'no error'
+    except RuntimeError as e:
+        twice = str(e)
+    assert 'released twice' in twice, twice
+    opt.step()                                                         # consumes it: the bucket may be released again
+    sync.bucket_ready(tw, 0)
+    # moments whose layout no longer matches the shard plan are never silently re-zeroed
+    m0 = opt._state[id(tw)][0]
+    opt._state[id(tw)] = (torch.zeros(m0.numel() + 64), torch.zeros(m0.numel() + 64))
+    try:
+        opt._moments(tw)
+        resized = 'no error'
+    except RuntimeError as e:
+        resized = str(e)
+    assert 'optimizer state of' in resized, resized
     q.put((rank, tw.flat.clone(), {k: {n: t.clone() for n, t in v.items()} for k, v in sd['state'].items()},
            opt._state[id(tw)][0].numel()))
     dist.barrier()
