@@ -230,6 +230,8 @@ def _sharded_worker(rank, world, rdzv, q):
         opt.step()
     sd = opt.state_dict()                                              # collective: gathers the ranks' m / v shards
     assert tw.dp.shard_elems * world == sum(b1 - b0 for (b0, b1), b in zip(_BUCKETS, tw.dp.buckets) if b is not None)
+    result = (rank, tw.flat.clone(), {k: {n: t.clone() for n, t in v.items()} for k, v in sd['state'].items()},
+              opt._state[id(tw)][0].numel())
     # a second backward before step() (gradient accumulation) would replace the un-consumed shard average: refused
     tw.flat_grad.add_(1.0)
     sync.bucket_ready(tw, 0)
@@ -250,8 +252,7 @@ def _sharded_worker(rank, world, rdzv, q):
     except RuntimeError as e:
         resized = str(e)
     assert 'optimizer state of' in resized, resized
-    q.put((rank, tw.flat.clone(), {k: {n: t.clone() for n, t in v.items()} for k, v in sd['state'].items()},
-           opt._state[id(tw)][0].numel()))
+    q.put(result)
     dist.barrier()
     dist.destroy_process_group()
 
