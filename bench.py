@@ -32,28 +32,26 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
-S_IMG = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24, mlp_ratio=4.0,
-             qkv_bias=True, repeated_times=2, use_transform=True)            # l_clip.yaml:4-17, image.yaml:5-23
-S_TXT = dict(depth=4, repeated_times=2, use_transform=True)                  # l_clip.yaml:18-23
-S_TXT_C = dict(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)      # text.yaml:6-10
-LOSS_DUAL = dict(loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})     # l_clip.yaml:29-32
-LOSS_ONE = dict(loss_name=['out_l1', 'out_cos'])                                                # image.yaml:25-26, text.yaml:12-13
+# model keyword arguments: the `model:` section of the reference's shipped YAMLs, extracted (values only) into
+# tests/golden/yaml_init_args.json by tools/golden/gen_yaml_init_args.py and bound through distillclip_amd.model.from_config,
+# the way `python main.py fit --conf <yaml>` binds them (l_clip.yaml:4-39, image.yaml:5-35, text.yaml:6-21)
+YAML_ARGS = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'yaml_init_args.json')))
 
 # step FLOP per unit: SURVEY.md §8d (teacher fwd + student fwd + student bwd = 2 x fwd)
 WORKLOADS = {
-    'lclip': dict(kind='dual', res=224, batch=512, unit='pairs', gflop=42.17,
+    'lclip': dict(kind='dual', yaml='l_clip', res=224, batch=512, unit='pairs', gflop=42.17,
                   metric='image-text pairs/sec (distill step)',
                   desc='l_clip.yaml dual distill: ViT-B/32 CLIP teacher -> weight-shared ViT(6x768,24h,R2) + text(4x768,12h,R2) '
                        'students, 224px/77tok, losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW'),
-    'lclip336': dict(kind='dual', res=336, batch=512, unit='pairs', gflop=65.98,
+    'lclip336': dict(kind='dual', yaml='l_clip', res=336, batch=512, unit='pairs', gflop=65.98,
                      metric='image-text pairs/sec (distill step, 336 px)',
                      desc='l_clip.yaml dual distill at 336x336 (101 image tokens; BASELINE configs[4] per-GPU share): same towers, '
                           'losses out_l1+out_cos+0.1*cos_diff, fwd+loss+bwd+AdamW'),
-    'image': dict(kind='image', res=224, batch=256, unit='images', gflop=22.65,
+    'image': dict(kind='image', yaml='image', res=224, batch=256, unit='images', gflop=22.65,
                   metric='images/sec (image.yaml distill step)',
                   desc='image.yaml: ViT-B/32 image teacher -> weight-shared ViT(6x768,24h,R2) student, freeze_embed, losses '
                        'out_l1+out_cos, fwd+loss+bwd+AdamW'),
-    'text': dict(kind='text', res=224, batch=1024, unit='captions', gflop=19.61,
+    'text': dict(kind='text', yaml='text', res=224, batch=1024, unit='captions', gflop=19.61,
                  metric='captions/sec (text.yaml distill step)',
                  desc='text.yaml: CLIP text teacher (12x512, causal) -> weight-shared text(4x768,12h,R2, compressed embedding) '
                       'student, 77 tok, losses out_l1+out_cos, fwd+loss+bwd+AdamW'),
@@ -67,31 +65,32 @@ def T(d):
 
 
 def build_model(wl, seed, device):
+    import copy
     from distillclip_amd import synth
-    from distillclip_amd.model import DualDistillModel, DistillModel
-    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    from distillclip_amd.model.from_config import instantiate
     tsd = synth.teacher_image_state(seed, resolution=wl['res'])
     tsd.update(synth.teacher_text_state(seed))
     tsd = T(tsd)
+    spec = copy.deepcopy(YAML_ARGS[wl['yaml']]['model'])
+    ia = spec['init_args']
     if wl['kind'] == 'dual':
-        cfg_i = dict(S_IMG, img_size=wl['res'])
-        s_img, s_txt = RepeatVisionTransformer(**cfg_i), RepeatTextTransformer(**S_TXT)
-        s_img.load_state_dict(T(synth.student_image_state(seed, **cfg_i)))
-        s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT)))
-        model = DualDistillModel(s_img, s_txt, LOSS_DUAL, warm_steps=15, total_steps=300, weight_decay=1e-3, lr=1e-4,
-                                 download_root='./.cache', teacher_state_dict=tsd)       # l_clip.yaml:35-39
-    elif wl['kind'] == 'image':
-        s_img = RepeatVisionTransformer(**S_IMG)
-        s_img.load_state_dict(T(synth.student_image_state(seed, **S_IMG)))
-        model = DistillModel(s_img, LOSS_ONE, './.cache', freeze_embed=True, teacher_need_layers=[0, 1, 10, 11],
-                             model_type='image', warm_steps=10, total_steps=200, weight_decay=1e-2, lr=5e-3,
-                             teacher_state_dict=tsd)                                     # image.yaml:24-35
+        ia['image_student']['init_args']['img_size'] = wl['res']          # configs[4]: the same YAML at 336 px
+        # load_path names the stage-1 checkpoints of a real run; the benchmark uses seeded synthetic weights instead
+        model = instantiate(spec, overrides={'load_path': None}, teacher_state_dict=tsd)
+        model.student.image_encoder.load_state_dict(T(synth.student_image_state(seed, **ia['image_student']['init_args'])))
+        model.student.text_encoder.load_state_dict(T(synth.student_text_state(seed, **ia['text_student']['init_args'])))
     else:
-        s_txt = RepeatTextTransformer(**S_TXT_C)
-        s_txt.load_state_dict(T(synth.student_text_state(seed, **S_TXT_C)))
-        model = DistillModel(s_txt, LOSS_ONE, './.cache', teacher_need_layers=[0, 1, 10, 11], model_type='text',
-                             warm_steps=10, total_steps=200, weight_decay=1e-2, lr=5e-3,
-                             teacher_state_dict=tsd)                                     # text.yaml:11-21
+        model = instantiate(spec, teacher_state_dict=tsd)
+        enc_args = {k: v for k, v in ia['student_encoder']['init_args'].items() if v is not None}
+        gen = synth.student_image_state if wl['kind'] == 'image' else synth.student_text_state
+        sd = T(gen(seed, **enc_args))
+        if wl['kind'] == 'image':
+            # freeze_embed copied the teacher's patch embedding into the student at construction (distil_model.py:200-213): keep it
+            frozen = {n for n, p in model.student.named_parameters() if not p.requires_grad}
+            sd = {k: v for k, v in sd.items() if k not in frozen}
+            model.student.load_state_dict(sd, strict=False)
+        else:
+            model.student.load_state_dict(sd)
     return model.to(device)
 
 
