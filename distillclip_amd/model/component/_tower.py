@@ -159,6 +159,14 @@ class HipTower:
                 out.append([off, end])
         return out
 
+    def sparse_spec(self):
+        """(bucket index, flat begin, rows, dim) of a token-embedding table whose gradient is row-sparse (the uncompressed text
+        student: reference weight_share_model.py:407, nn.Embedding(49408, 768)), else None"""
+        if self.cfg.modality != 1 or self.cfg.kind != 1 or self.cfg.embed_rank != 0:
+            return None
+        offs = self.param_offsets()
+        return lib().dclip_encoder_num_grad_buckets(self._handle) - 1, offs[0], self.cfg.vocab, self.cfg.width
+
     def attach_grads(self):
         """Make p.grad views of the flat gradient buffer.  If any trainable p.grad was dropped (zero_grad(set_to_none)),
         the buffer is zeroed first — the kernels accumulate with +=, like autograd does into an existing .grad."""
@@ -233,6 +241,8 @@ class HipTower:
         if ev is not None:                         # an optimizer update of these weights may still be running on another stream
             torch.cuda.current_stream().wait_event(ev)
         B = x.shape[0]
+        if training and self.dp is not None and self.sync is not None and self.sync.enabled:
+            self.sync.note_token_ids(self, x)      # text student: the global batch's token ids, for the row-sparse table exchange
         if self.wcache_dirty or (self._prepare_always and (training or any(p.requires_grad for p in self.module.parameters()))):
             self.prepare()      # trainable towers: the optimizer moved the f32 masters since the last cast
         self._ensure_workspace(B, training, x.device)

@@ -86,7 +86,8 @@ class FusedAdamW:
         from .parallel import all_gather_flat
         sync = tw.sync
         m, v = self._moments(tw)
-        s = sync.stream_for(tw.flat)
+        s = sync.stream_for(tw.flat, tw)
+        grp = sync.group_for(tw)
         if s is not None:
             # whatever the caller's stream holds before step() must be visible on the exchange stream — in particular the
             # zero-fill of freshly allocated m / v (first step): without this edge AdamW read uninitialised moments at world
@@ -102,7 +103,7 @@ class FusedAdamW:
                 for a, e in own_tr:
                     lo, hi = off + a - o0, off + e - o0
                     self._adamw(tw.flat[a:e], tw.gshard[lo:hi], m[lo:hi], v[lo:hi], False, st)
-                works.append(all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True))
+                works.append(all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True, group=grp))
             for w in works:
                 if w is not None:
                     w.wait()

@@ -30,33 +30,42 @@ def _native():
     return dist.get_backend() == 'nccl'
 
 
-def reduce_scatter_avg(out, inp):
+def reduce_scatter_avg(out, inp, group=None):
     """out <- this rank's 1/W slice of the element-wise average of `inp` over the ranks"""
     world, rank = dist.get_world_size(), dist.get_rank()
     if _native():
-        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG)
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=group)
         return
     n = out.numel()
     if not inp.is_cuda:
         try:
-            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
             out.mul_(1.0 / world)
             return
         except RuntimeError:
             pass
     tmp = inp.clone()
-    dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
     out.copy_(tmp[rank * n:(rank + 1) * n]).mul_(1.0 / world)
 
 
-def all_gather_flat(out, inp, async_op=False):
+def all_reduce_avg(t, group=None):
+    """t <- element-wise average over the ranks, in place"""
+    if _native():
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t.mul_(1.0 / dist.get_world_size())
+
+
+def all_gather_flat(out, inp, async_op=False, group=None):
     """out[r * n:(r + 1) * n] <- rank r's `inp` (out may contain inp in place)"""
     if _native() or not inp.is_cuda:
-        return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+        return dist.all_gather_into_tensor(out, inp, async_op=async_op, group=group)
     rank, n = dist.get_rank(), inp.numel()
     tmp = torch.zeros_like(out)
     tmp[rank * n:(rank + 1) * n].copy_(inp)
-    dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
     out.copy_(tmp)
     return None
 
@@ -107,8 +116,14 @@ class GradSync:
         # while armed, i.e. inside backward_and_sync(): a bare loss.backward() leaves p.grad whole for whoever consumes it
         # (gradient clipping, grad-norm logging, a DDP wrapper, a torch optimizer).
         self.armed = False
-        self._stream = None
+        # one exchange stream AND one communicator per tower: the image tower's buckets do not queue behind the text tower's
+        # embedding bucket (collectives of one communicator execute in issue order)
+        self._streams = {}
+        self._groups = {}
+        self._stream = None                      # (flat all-reduce fallback)
         self._pending = []
+        # token-embedding table of the (uncompressed) text student: exchange only the rows the global batch touched
+        self.sparse_embedding = os.environ.get('DCLIP_DP_SPARSE_EMBED', '1') != '0'
 
     @staticmethod
     def current(existing=None):
@@ -123,12 +138,23 @@ class GradSync:
             tw.sync = self
             if self.enabled and self.sharded and tw.dp is None and tw.flat is not None:
                 self.plan(tw, tw.trainable_ranges())
+            if self.enabled and self.sharded and id(tw) not in self._groups:
+                # collective: every rank attaches its towers in the same order
+                self._groups[id(tw)] = dist.new_group() if os.environ.get('DCLIP_DP_TOWER_GROUPS', '1') != '0' else None
         return self
 
+    def group_for(self, tw):
+        return self._groups.get(id(tw))
+
     # ---- stream plumbing (no-ops for the gloo / CPU rehearsal of the same call pattern) ---------------------------
-    def stream_for(self, t):
+    def stream_for(self, t, tw=None):
         if not t.is_cuda:
             return None
+        if tw is not None:
+            s = self._streams.get(id(tw))
+            if s is None:
+                s = self._streams[id(tw)] = torch.cuda.Stream(device=t.device)
+            return s
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=t.device)
         return self._stream
@@ -172,24 +198,105 @@ class GradSync:
         tw.dp_unstepped.add(i)
         b0, b1, o0, o1, off, _ = b
         g = tw.flat_grad
-        s = self.stream_for(g)
+        s = self.stream_for(g, tw)
         if s is not None:
             if after is None:
                 after = torch.cuda.Event()
                 after.record(torch.cuda.current_stream())
             s.wait_event(after)
         with GradSync._On(s):
-            reduce_scatter_avg(tw.gshard[off:off + (o1 - o0)], g[b0:b1])
-            g[b0:b1].zero_()                            # the backward accumulates (+=): leave the bucket clean for the next step
+            sp = getattr(tw, '_sparse', None)
+            if sp is not None and sp['bucket'] == i:
+                self._release_sparse(tw, b, sp)
+                tw._sparse = None
+            else:
+                reduce_scatter_avg(tw.gshard[off:off + (o1 - o0)], g[b0:b1], group=self.group_for(tw))
+                g[b0:b1].zero_()                        # the backward accumulates (+=): leave the bucket clean for the next step
+
+    # ---- row-sparse exchange of the token-embedding gradient (reference weight_share_model.py:407) ----
+    def note_token_ids(self, tw, ids):
+        """Forward time, text student with a plain (uncompressed) embedding table: the gradient of the [V, D] table is non-zero only
+        in the rows of the token ids of the GLOBAL batch.  The ranks exchange their ids ([B, 77] int32 each), every rank builds
+        the same sorted union with static shapes (sort, first-occurrence flags, prefix sum: no host synchronisation) and the row
+        count travels to pinned host memory; by the time the embedding bucket is released at the end of the backward it has
+        long arrived, and the collective over the compacted rows can be sized on the host."""
+        spec = tw.sparse_spec() if hasattr(tw, 'sparse_spec') else None
+        if spec is None or not (self.enabled and self.sharded and self.sparse_embedding) or tw.dp is None:
+            return
+        bucket, t0, V, D = spec
+        if tw.dp.buckets[bucket] is None:
+            return
+        loc = ids.reshape(-1).to(torch.int32)
+        s = self.stream_for(loc, tw)
+        if s is not None:
+            s.wait_stream(torch.cuda.current_stream())
+        with GradSync._On(s):
+            n = loc.numel()
+            allids = torch.empty(self.world * n, dtype=torch.int32, device=loc.device)
+            all_gather_flat(allids, loc.contiguous(), group=self.group_for(tw))
+            srt = torch.sort(allids.long()).values
+            first = torch.ones_like(srt, dtype=torch.bool)
+            first[1:] = srt[1:] != srt[:-1]
+            pos = torch.cumsum(first.to(torch.int64), 0) - 1
+            uniq = torch.full((min(V, self.world * n),), V - 1, dtype=torch.int64, device=loc.device)
+            uniq.scatter_(0, pos, srt)                   # duplicates write the same value to the same slot
+            count = (pos[-1:] + 1).to(torch.int64)
+            if loc.is_cuda:
+                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                host.copy_(count, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s)
+            else:
+                host, ev = count.clone(), None
+        tw._sparse = dict(bucket=bucket, t0=t0, V=V, D=D, uniq=uniq, count=host, event=ev)
+
+    def _release_sparse(self, tw, b, sp):
+        """(on the tower's exchange stream) average the touched table rows over the ranks, write this rank's shard of the bucket
+        (zeros in the untouched rows, bit-identical to the dense reduce-scatter in the touched ones), clear the touched rows"""
+        b0, b1, o0, o1, off, _ = b
+        if sp['event'] is not None:
+            sp['event'].synchronize()                   # recorded at forward time: done long ago
+        n = int(sp['count'].item())
+        t0, V, D = sp['t0'], sp['V'], sp['D']
+        t1 = t0 + V * D
+        g = tw.flat_grad
+        grp = self.group_for(tw)
+        shard = tw.gshard[off:off + (o1 - o0)]
+        shard.zero_()
+        rows = sp['uniq'][:n]
+        table = g[t0:t1].view(V, D)
+        compact = table.index_select(0, rows)            # [n, D]
+        all_reduce_avg(compact, group=grp)
+        # owned part of the table: flat [lo, hi) -> rows [r_lo, r_hi) (the shard boundary may cut a row)
+        lo, hi = max(o0, t0), min(o1, t1)
+        if lo < hi:
+            r_lo, r_hi = (lo - t0) // D, (hi - t0 + D - 1) // D
+            inside = ((rows >= r_lo) & (rows < r_hi)).to(compact.dtype).unsqueeze(1)
+            buf = torch.zeros((r_hi - r_lo, D), dtype=compact.dtype, device=compact.device)
+            buf.index_add_(0, (rows - r_lo).clamp_(0, r_hi - r_lo - 1), compact * inside)     # rows outside add 0 to a clamped slot
+            start = lo - (t0 + r_lo * D)
+            shard[lo - o0:hi - o0].copy_(buf.view(-1)[start:start + (hi - lo)])
+        table.index_fill_(0, rows, 0.0)                  # the backward accumulates (+=): touched rows clean for the next step
+        # the rest of the bucket (positional embedding, ...) is small and dense
+        for a, e in ((b0, t0), (t1, b1)):
+            if a < e:
+                rest = g[a:e]
+                all_reduce_avg(rest, group=grp)
+                x0, x1 = max(a, o0), min(e, o1)
+                if x0 < x1:
+                    shard[x0 - o0:x1 - o0].copy_(g[x0:x1])
+                rest.zero_()
+        tw.sparse_rows_last = n                         # (diagnostics / tests: rows exchanged instead of V)
 
     def finish(self, tw):
         """after the backward call: release whatever the callbacks did not (a backward without per-bucket callbacks)"""
         for i in range(tw.dp_released, len(tw.dp.buckets)):
             self.bucket_ready(tw, i, after=getattr(tw, 'bwd_done', None))
         tw.dp_released = 0
-        if tw.flat_grad.is_cuda and self._stream is not None:
+        s = self._streams.get(id(tw))
+        if tw.flat_grad.is_cuda and s is not None:
             done = torch.cuda.Event()
-            done.record(self._stream)
+            done.record(s)
             return done
         return None
 
@@ -199,14 +306,14 @@ class GradSync:
         if b is None:
             return
         b0, b1, o0, o1, _, _ = b
-        all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1])
+        all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], group=self.group_for(tw))
 
     def gather_full(self, tw, shard):
         """[shard_elems] per-rank optimizer state -> full flat-layout tensor (checkpointing; collective)"""
         full = torch.zeros_like(tw.flat)
         for b in tw.dp.live():
             b0, b1, o0, o1, off, _ = b
-            all_gather_flat(full[b0:b1], shard[off:off + (o1 - o0)].contiguous())
+            all_gather_flat(full[b0:b1], shard[off:off + (o1 - o0)].contiguous(), group=self.group_for(tw))
         return full
 
     # ---- flat all-reduce (fallback; the reference's DDP semantics literally) -----------------------------------------------
@@ -236,8 +343,9 @@ class GradSync:
                 chunk.mul_(1.0 / self.world)
 
     def wait(self):
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
+        for s in [self._stream] + list(self._streams.values()):
+            if s is not None:
+                torch.cuda.current_stream().wait_stream(s)
         self._pending = []
 
     def forget(self):

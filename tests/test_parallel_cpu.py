@@ -290,6 +290,68 @@ def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded_world2():
             assert float(st[i]['step']) == 3.0
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# row-sparse exchange of the token-embedding gradient (reference weight_share_model.py:407: nn.Embedding(49408, 768))
+# ---------------------------------------------------------------------------------------------------------------------
+_SV, _SD = 40, 24                                   # table rows / width: the shard boundary (512) cuts row 21
+_S_TOTAL = 1024 + 128
+_S_BUCKETS = [(1024, 1152), (0, 1024)]              # a block bucket, then the embedding bucket: table [0, 960) + positions [960, 1024)
+
+
+class _FakeTextTower(_FakeTower):
+    def sparse_spec(self):
+        return 1, 0, _SV, _SD
+
+
+def _sparse_worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
+    from distillclip_amd.parallel import GradSync
+    out = {}
+    for mode in ('sparse', 'dense'):
+        tw = _FakeTextTower(_S_TOTAL, _S_BUCKETS, [[0, _S_TOTAL]], seed=5)
+        sync = GradSync()
+        sync.sparse_embedding = mode == 'sparse'
+        sync.attach([tw])
+        gen = torch.Generator().manual_seed(40 + rank)
+        ids = torch.randint(0, _SV, (3, 4), generator=gen)              # this rank's token ids: at most 12 of the 40 rows
+        g = torch.zeros(_S_TOTAL)
+        rows = torch.unique(ids.reshape(-1))
+        g[:_SV * _SD].view(_SV, _SD)[rows] = torch.randn(len(rows), _SD, generator=gen)
+        g[_SV * _SD:] = torch.randn(_S_TOTAL - _SV * _SD, generator=gen)
+        tw.flat_grad.copy_(g)
+        sync.note_token_ids(tw, ids)                                    # what HipTower.forward does
+        assert (getattr(tw, '_sparse', None) is not None) == (mode == 'sparse')
+        for i in range(len(_S_BUCKETS)):
+            sync.bucket_ready(tw, i)
+        sync.finish(tw)
+        assert float(tw.flat_grad.abs().max()) == 0.0                   # exchanged buckets are left clean either way
+        out[mode] = tw.gshard.clone()
+        if mode == 'sparse':
+            out['rows'] = tw.sparse_rows_last
+            out['ids'] = ids
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sparse_embedding_exchange_equals_dense_reduce_scatter_world2():
+    res = sorted(_run_ranks(_sparse_worker, 2, timeout=90), key=lambda r: r[0])
+    union = torch.unique(torch.cat([o['ids'].reshape(-1) for _, o in res]))
+    for rank, o in res:
+        assert torch.equal(o['sparse'], o['dense']), (rank, (o['sparse'] - o['dense']).abs().max())     # bit for bit
+        assert o['rows'] == len(union) < _SV                            # only the touched rows travelled
+    # ... and the untouched rows of the owned table slice are exactly zero in the shard
+    per = 1024 // 2
+    for rank, o in res:
+        emb = o['sparse'][128 // 2:]                                    # shard layout: block bucket first, then the embedding bucket
+        lo = rank * per
+        for r in range(_SV):
+            a, b = max(r * _SD, lo), min((r + 1) * _SD, lo + per)
+            if a < b and r not in union.tolist():
+                assert float(emb[a - lo:b - lo].abs().max()) == 0.0
+
+
 def test_shard_plan_rejects_indivisible_world():
     from distillclip_amd.parallel import _Shards
     with pytest.raises(ValueError, match='not divisible'):

@@ -9,7 +9,6 @@ and only the wire is different (parallel.py routes reduce-scatter / all-gather t
   * global negatives (north-star mode): 2 ranks == one process on the concatenated batch (SURVEY.md section 8e parity statement).
 """
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -31,14 +30,6 @@ def T(d):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _build(loss):
     from distillclip_amd.model import DualDistillModel
     from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
@@ -56,11 +47,11 @@ def _data():
     return image, text
 
 
-def _rank(rank, world, port, loss, global_neg, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _rank(rank, world, rdzv, loss, global_neg, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)    # FileStore: no port to race for
     model = _build(loss)
     model.loss_control.global_negatives = global_neg
     (opt,), _ = model.configure_optimizers()            # GradSync (world 2): shard plan of both towers
@@ -78,6 +69,8 @@ def _rank(rank, world, port, loss, global_neg, q):
     opt.join()
     torch.cuda.synchronize()
     assert float(tw.flat_grad.abs().max()) == 0.0
+    ttw = model.towers()[1]                                       # text student: its embedding bucket travelled row-sparse
+    assert float(ttw.flat_grad.abs().max()) == 0.0 and 0 < ttw.sparse_rows_last < ttw.cfg.vocab
     m_elems = opt._state[id(tw)][0].numel()
     sd = opt.state_dict()                                         # collective: gathers the moment shards
     # plain numpy through the queue (torch tensors travel as shared-memory handles that die with the rank)
@@ -88,16 +81,24 @@ def _rank(rank, world, port, loss, global_neg, q):
 
 
 def _run_ranks(loss, global_neg):
+    import shutil
+    import tempfile
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_rank, args=(r, 2, port, loss, global_neg, q)) for r in range(2)]
+    d = tempfile.mkdtemp(prefix='dclip_rdzv_')
+    ps = [ctx.Process(target=_rank, args=(r, 2, os.path.join(d, 'store'), loss, global_neg, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in ps], key=lambda r: r[0])
-    for p in ps:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=600) for _ in ps], key=lambda r: r[0])
+        for p in ps:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+        shutil.rmtree(d, ignore_errors=True)
     return res
 
 
