@@ -41,6 +41,49 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         }
 }
 
+// Multi-tensor form of the above (the per-step refresh of a student's bf16 weight cache: one launch per tower instead of one
+// per weight): up to CT_MAXJ jobs per launch, every R and C a multiple of 64; float4 reads, 8-byte bf16 stores both ways.
+constexpr int CT_MAXJ = 24;
+struct CastJobs {
+    const float* W[CT_MAXJ];
+    bf16_t* Wb[CT_MAXJ];
+    bf16_t* Wt[CT_MAXJ];
+    int R[CT_MAXJ], C[CT_MAXJ];
+    int tile_end[CT_MAXJ];             // running count of 64 x 64 tiles
+    int n;
+};
+
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CastJobs jb) {
+    __shared__ __attribute__((aligned(8))) bf16_t tile[64][68];
+    int j = 0;
+    while (j + 1 < jb.n && (int)blockIdx.x >= jb.tile_end[j]) ++j;
+    const int t = blockIdx.x - (j ? jb.tile_end[j - 1] : 0);
+    const int R = jb.R[j], C = jb.C[j];
+    const int tc = C >> 6;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const float* __restrict__ W = jb.W[j];
+    bf16_t* __restrict__ Wb = jb.Wb[j];
+    bf16_t* __restrict__ Wt = jb.Wt[j];
+    const int q = (threadIdx.x & 15) * 4, y = threadIdx.x >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = y + 16 * k;
+        const float4 v = *(const float4*)(W + (int64_t)(r0 + r) * C + c0 + q);
+        const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+        if (Wb) *(bf16x4*)(Wb + (int64_t)(r0 + r) * C + c0 + q) = o;
+        *(bf16x4*)&tile[r][q] = o;
+    }
+    __syncthreads();
+    if (Wt) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = y + 16 * k;
+            const bf16x4 o = {tile[q][c], tile[q + 1][c], tile[q + 2][c], tile[q + 3][c]};
+            *(bf16x4*)(Wt + (int64_t)(c0 + c) * R + r0 + q) = o;
+        }
+    }
+}
+
 // img f32 [B,C,res,res] -> rows bf16 [B*(G*G+cls), C*p*p]; row (b, cls + py*G + px), col (c, ky, kx)
 // (reference _common.py:196-198 / timm PatchEmbed: Conv2d(k=p, s=p) == im2row + GEMM; the trailing res % p pixels
 // are dropped exactly like the strided conv does).  cls rows are zero so the GEMM emits 0 there.
@@ -278,6 +321,33 @@ extern "C" int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
     hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)Wb, (bf16_t*)Wt, (int)R, (int)C);
     return dclip_check_launch("dclip_cast_transpose_bf16");
+}
+
+extern "C" int dclip_cast_transpose_bf16_multi(const float* const* W, void* const* Wb, void* const* Wt, const int64_t* R,
+                                               const int64_t* C, int64_t n, void* stream) {
+    DCLIP_REQUIRE(W && Wb && Wt && R && C && n > 0, "dclip_cast_transpose_bf16_multi: bad argument");
+    CastJobs jb;
+    jb.n = 0;
+    int tiles = 0;
+    auto flush = [&]() {
+        if (jb.n) hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, jb);
+        jb.n = 0; tiles = 0;
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        DCLIP_REQUIRE(W[i] && (Wb[i] || Wt[i]) && R[i] > 0 && C[i] > 0, "dclip_cast_transpose_bf16_multi: bad job %ld", (long)i);
+        if (R[i] % 64 || C[i] % 64) {                    // odd shapes: the single-tensor kernel
+            hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)((C[i] + 63) / 64), (unsigned)((R[i] + 63) / 64)), dim3(256), 0,
+                               (hipStream_t)stream, W[i], (bf16_t*)Wb[i], (bf16_t*)Wt[i], (int)R[i], (int)C[i]);
+            continue;
+        }
+        if (jb.n == CT_MAXJ) flush();
+        const int k = jb.n++;
+        jb.W[k] = W[i]; jb.Wb[k] = (bf16_t*)Wb[i]; jb.Wt[k] = (bf16_t*)Wt[i]; jb.R[k] = (int)R[i]; jb.C[k] = (int)C[i];
+        tiles += (int)((R[i] / 64) * (C[i] / 64));
+        jb.tile_end[k] = tiles;
+    }
+    flush();
+    return dclip_check_launch("dclip_cast_transpose_bf16_multi");
 }
 
 extern "C" int dclip_im2row(const float* img, void* rows, int64_t B, int64_t C, int64_t res, int64_t patch, int cls_rows,

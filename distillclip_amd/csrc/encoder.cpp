@@ -301,21 +301,25 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
     bf16_t* W = (bf16_t*)wcache;
     const int64_t D = p.D, F = p.F, E = p.E;
     auto at = [&](int64_t off) -> void* { return off < 0 ? nullptr : (void*)(W + off); };
+    // one multi-tensor launch for the whole tower (students refresh their cache every step: 14 / 9 launches became 1)
+    std::vector<const float*> src; std::vector<void*> wb, wt; std::vector<int64_t> rr, cc;
+    auto job = [&](const float* w, void* b, void* t, int64_t R, int64_t C) { src.push_back(w); wb.push_back(b); wt.push_back(t); rr.push_back(R); cc.push_back(C); };
     for (int l = 0; l < p.L; ++l) {
         const auto& b = p.bw[l];
         int iq, ip, i1, i2;
         if (p.student) { SB s = sblock(p, l); iq = s.qkvw; ip = s.prw; i1 = s.f1w; i2 = s.f2w; }
         else { TB t = tblock(p, l); iq = t.inw; ip = t.outw; i1 = t.fcw; i2 = t.prw; }
-        CK(dclip_cast_transpose_bf16(PF(params, iq), at(b.qkv), at(b.qkv_t), 3 * D, D, st));
-        CK(dclip_cast_transpose_bf16(PF(params, ip), at(b.proj), at(b.proj_t), D, D, st));
-        CK(dclip_cast_transpose_bf16(PF(params, i1), at(b.fc1), at(b.fc1_t), F, D, st));
-        CK(dclip_cast_transpose_bf16(PF(params, i2), at(b.fc2), at(b.fc2_t), D, F, st));
+        job(PF(params, iq), at(b.qkv), at(b.qkv_t), 3 * D, D);
+        job(PF(params, ip), at(b.proj), at(b.proj_t), D, D);
+        job(PF(params, i1), at(b.fc1), at(b.fc1_t), F, D);
+        job(PF(params, i2), at(b.fc2), at(b.fc2_t), D, F);
     }
-    if (p.image) CK(dclip_cast_bf16(PF(params, 0), at(p.w_embed), D * p.K, st));                // conv weight [D, C*p*p]
-    else if (p.compressed) CK(dclip_cast_transpose_bf16(PF(params, 1), at(p.w_embed), at(p.w_embed_t), D, p.c.embed_rank, st));
-    if (p.student) CK(dclip_cast_transpose_bf16(PF(params, p.p_final + 2), at(p.w_head), at(p.w_head_t), E, D, st));
-    else CK(dclip_cast_transpose_bf16(PF(params, p.p_final + 2), nullptr, at(p.w_head), D, E, st));   // proj [D,E] -> [E,D]
-    return DCLIP_OK;
+    if (p.image) job(PF(params, 0), at(p.w_embed), nullptr, D, p.K);                          // conv weight [D, C*p*p]
+    else if (p.compressed) job(PF(params, 1), at(p.w_embed), at(p.w_embed_t), D, p.c.embed_rank);
+    if (p.student) job(PF(params, p.p_final + 2), at(p.w_head), at(p.w_head_t), E, D);
+    else job(PF(params, p.p_final + 2), nullptr, at(p.w_head), D, E);                         // proj [D,E] -> [E,D]
+    for (size_t i = 0; i < src.size(); ++i) DCLIP_REQUIRE(src[i], "dclip_encoder_prepare: parameter %zu missing", i);
+    return dclip_cast_transpose_bf16_multi(src.data(), wb.data(), wt.data(), rr.data(), cc.data(), (int64_t)src.size(), st);
 }
 
 extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,

@@ -234,3 +234,17 @@ def attn_mix_bwd(qkv, d_ctx, B, N, H, hd, wl, ww, stats, scale, dwl, dww):
     lib().dclip_attn_mix_bwd(_p(qkv), qkv.stride(0), _p(d_ctx), d_ctx.stride(0), _p(wl), _p(ww), _p(stats), _p(ds), _p(dwl), _p(dww),
                              _p(ws), ws.numel(), B, H, N, Np, hd, scale, _stream())
     return ds
+
+
+def cast_transpose_multi(ws, want_b=True, want_t=True):
+    """[W f32 [R, C]] -> ([bf16 [R, C]] or None, [bf16 [C, R]] or None) in ONE launch (include/dclip.h: dclip_cast_transpose_bf16_multi)"""
+    import ctypes
+    _chk(*ws)
+    n = len(ws)
+    wb = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws] if want_b else [None] * n
+    wt = [torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device) for w in ws] if want_t else [None] * n
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    R = (ctypes.c_int64 * n)(*[w.shape[0] for w in ws])
+    C = (ctypes.c_int64 * n)(*[w.shape[1] for w in ws])
+    lib().dclip_cast_transpose_bf16_multi(arr(ws), arr(wb), arr(wt), R, C, n, _stream())
+    return (wb if want_b else None), (wt if want_t else None)

@@ -176,6 +176,10 @@ int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src (row length D) */
 int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream);
 int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream);
+/* n jobs of the above in one launch (per-step refresh of a student tower's bf16 weight cache): host arrays of device pointers
+ * and shapes; Wb[i] / Wt[i] nullable per job. */
+int dclip_cast_transpose_bf16_multi(const float* const* W, void* const* Wb, void* const* Wt, const int64_t* R, const int64_t* C,
+                                    int64_t n, void* stream);
 int dclip_im2row(const float* img, void* rows, int64_t B, int64_t C, int64_t res, int64_t patch, int cls_rows, void* stream);
 int dclip_token_table(const float* pos, const float* cls, const float* bias, float* out, int64_t ntok, int64_t D, void* stream);
 int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D, int has_cls,

@@ -281,3 +281,16 @@ def test_fused_student_attention_support_matrix():
     assert lib().dclip_attn_student_fwd_supported(24, 50, 32) and lib().dclip_attn_student_fwd_supported(12, 77, 64)
     assert not lib().dclip_attn_student_fwd_supported(12, 50, 64) and not lib().dclip_attn_student_fwd_supported(8, 77, 64)
     assert not lib().dclip_attn_student_fwd_supported(24, 65, 32) and not lib().dclip_attn_student_fwd_supported(12, 129, 64)
+
+
+def test_multi_tensor_cast_transpose():
+    """dclip_cast_transpose_bf16_multi (the per-step bf16 weight-cache refresh of a student tower, one launch): every job equals
+    the f32 -> bf16 cast and its transpose exactly; more jobs than one launch holds; an odd shape takes the single-tensor kernel"""
+    from distillclip_amd import ops
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (512, 768), (64, 64), (100, 72)] + [(128, 64 * (1 + i % 3)) for i in range(30)]
+    ws = [_randn(sh, 70 + i) for i, sh in enumerate(shapes)]
+    wb, wt = ops.cast_transpose_multi(ws)
+    for w, b, t in zip(ws, wb, wt):
+        assert torch.equal(b, w.bfloat16()) and torch.equal(t, w.bfloat16().t().contiguous())
+    _, wt2 = ops.cast_transpose_multi(ws[:3], want_b=False)
+    assert all(torch.equal(a, b) for a, b in zip(wt2, wt[:3]))
