@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
                 bf16x4 pv = {f2bf(st[jt][0] * inv), f2bf(st[jt][1] * inv), f2bf(st[jt][2] * inv), f2bf(st[jt][3] * inv)};
                 *(bf16x4*)(pt + fr * prowb + (jt * 16 + g * 4) * 2) = pv;
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // wave-private tile, in-order DS queue: only the compiler has to keep the order (a workgroup-scope release fence would also
+        // wait for vmcnt(0), i.e. for the next tile's query fragments that were requested at the top of the iteration)
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // O^T[d, i] = sum_j V[j, d] P[i, j]
         f32x4 oc[DT];

@@ -142,6 +142,7 @@ struct Work {
     float* tok_sum; float* demb;           // [N, D] ; compressed: [M, rank] f32
     float* wg_dummy;                       // [2, H, H] sink for conv_l / conv_w gradients when those parameters are frozen
     float* mix_ws; size_t mix_ws_bytes;    // per-workgroup weight-gradient partials of dclip_attn_mix_bwd
+    void* tn_ws; size_t tn_ws_bytes;       // partial tiles of the 256 x 256 wgrad launches (dclip_gemm_tn_acc)
     size_t bytes;
 };
 
@@ -202,10 +203,12 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         w.wg_dummy = b.take<float>(2 * p.H * p.H);
         w.mix_ws_bytes = p.c.head_mix ? dclip_attn_mix_bwd_workspace_bytes(B, p.H, N) : 0;
         w.mix_ws = w.mix_ws_bytes ? (float*)b.take<char>(w.mix_ws_bytes) : nullptr;
+        w.tn_ws_bytes = dclip_gemm_tn_workspace_bytes();
+        w.tn_ws = b.take<char>(w.tn_ws_bytes);
         w.demb = p.compressed ? b.take<float>(M * p.c.embed_rank) : nullptr;
     } else {
         w.G = nullptr; w.Gb = nullptr; w.gb_f2 = w.gb_pr = nullptr; w.dbig = w.dh = w.dqkv = w.dR = w.dS = w.dout = nullptr; w.tok_sum = w.demb = nullptr; w.wg_dummy = nullptr;
-        w.mix_ws = nullptr; w.mix_ws_bytes = 0;
+        w.mix_ws = nullptr; w.mix_ws_bytes = 0; w.tn_ws = nullptr; w.tn_ws_bytes = 0;
     }
     w.bytes = b.off;
 }
@@ -472,7 +475,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     // ---- head + final norm -----------------------------------------------------------------------------------
     const int f = p.p_final;
     CK(dclip_cast_bf16(d_last_representation, w.dout, B * E, st));
-    if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, st));
+    if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, w.tn_ws, w.tn_ws_bytes, st));
     if (GR(f + 3)) CK(dclip_colsum_acc(w.dout, E, GR(f + 3), B, E, st));
     CK(gemm(w.dout, E, W + p.w_head_t, E, w.dh, D, B, D, E, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
     // every LayerNorm backward also emits the column sums of the updated residual gradient = the bias gradient of the
@@ -505,13 +508,13 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         CK(dclip_gemm_nt(gb_f2, D, W + bw.fc2_t, D, dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_MULAUX, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
                          GR(sb.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
-        if (r == 0 && GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(sb.f2w), F, MR, D, F, wsplits(MR, D, F), st));
-        if (r == 0 && GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(sb.f1w), D, MR, F, D, wsplits(MR, F, D), st));
+        if (r == 0 && GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(sb.f2w), F, MR, D, F, wsplits(MR, D, F), w.tn_ws, w.tn_ws_bytes, st));
+        if (r == 0 && GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(sb.f1w), D, MR, F, D, wsplits(MR, F, D), w.tn_ws, w.tn_ws_bytes, st));
         CK(gemm(dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(sr.n2w), GR(sr.n2b),
                                GR(sb.prb), M, D, st));
         // attention: x_mid = x_in + proj(attn(LN1(x_in)))
-        if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), st));
+        if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), w.tn_ws, w.tn_ws_bytes, st));
         bf16_t* dctx = w.dh;
         CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         const int blk = (wl && mix_attn(p, N)) ? 1 : 0;        // R and dS of the register-resident score stage are quad-blocked
@@ -527,7 +530,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
         }
         CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dQ = dS K
         CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dK = dS^T Q
-        if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), st));
+        if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), w.tn_ws, w.tn_ws_bytes, st));
         if (r == 0 && params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), MR, 3 * D, st));
         CK(gemm(dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         // the bf16 residual gradient leaving this execution is the fc2 operand of the previous one (slot of its repeat index)
@@ -543,14 +546,14 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     if (d_emb) CK(dclip_axpy_f32(w.G, d_emb, w.Gb, M * D, nullptr, D, st));
     if (hipMemsetAsync(w.tok_sum, 0, (size_t)N * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
     if (p.image) {           // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
-        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), st));
+        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), w.tn_ws, w.tn_ws_bytes, st));
         if (GR(1) || GR(2) || GR(3)) {
             CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
             CK(dclip_token_table_bwd(w.tok_sum, GR(3), GR(2), GR(1), N, D, 1, st));
         }
     } else if (p.compressed) {   // grads: 0 table, 1 linear w, 2 linear b, 3 pos
         const int64_t rk = p.c.embed_rank;
-        if (GR(1)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, rk, GR(1), rk, M, D, rk, wsplits(M, D, rk), st));
+        if (GR(1)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, rk, GR(1), rk, M, D, rk, wsplits(M, D, rk), w.tn_ws, w.tn_ws_bytes, st));
         if (GR(2) || GR(3)) {
             CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
             CK(dclip_token_table_bwd(w.tok_sum, GR(3), nullptr, GR(2), N, D, 0, st));

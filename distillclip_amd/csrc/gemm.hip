@@ -624,6 +624,7 @@ struct GemmTN {
     int M, P, Q;
     int tiles_p, tiles_q, splits, chunk;            // chunk = rows of M per split (multiple of TC)
     unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps), else null
+    float* partial;                                 // 256^2 wgrad: [splits][tiles][256][256] f32 partial tiles (null: f32 atomics)
 };
 
 // load a [64 x 128] bf16 tile (rows m0.., cols c0..) into registers: 4 x 16 B per thread
@@ -999,15 +1000,45 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
                 for (int r = 0; r < 4; ++r)
                     cs[(wr * 32 + i * 16 + (lane >> 4) * 4 + r) * CL + wc * 64 + j * 16 + (lane & 15)] = acc[q * 2 + i][j][r];
         __syncthreads();
+        if (p.partial) {
+            // partial tile with plain 16-byte stores (the chip adds f32 atomics at ~1.3 TB/s, stores run at ~6): the splits of a
+            // tile are summed into dW by tn256_reduce_kernel afterwards, in a fixed order -> run-to-run identical gradients
+            float* dst = p.partial + ((int64_t)split * tiles + tile) * 65536;
 #pragma unroll 4
-        for (int it = 0; it < 32; ++it) {
-            const int sl = (tid >> 8) + it * 2;                          // slab row 0..63, 256 threads per row
-            const int row = p0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
-            const int col = q0 + (tid & 255);
-            unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, cs[sl * CL + (tid & 255)]);
+            for (int it = 0; it < 8; ++it) {
+                const int sl = (tid >> 6) + it * 8;                      // slab row 0..63, 64 threads x float4 per row
+                const int rt = (sl >> 5) * 128 + q * 32 + (sl & 31);     // row inside the tile
+                *(float4*)(dst + rt * 256 + (tid & 63) * 4) = *(const float4*)&cs[sl * CL + (tid & 63) * 4];
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int sl = (tid >> 8) + it * 2;                          // slab row 0..63, 256 threads per row
+                const int row = p0 + (sl >> 5) * 128 + q * 32 + (sl & 31);
+                const int col = q0 + (tid & 255);
+                unsafeAtomicAdd(p.out + (int64_t)row * p.ldo + col, cs[sl * CL + (tid & 255)]);
+            }
         }
     }
     stamp(3);
+}
+
+// dW[row, col .. col + 3] += sum over the splits of the partial tiles written by gemm_tn256_kernel (fixed order)
+__global__ __launch_bounds__(256) void tn256_reduce_kernel(const float* __restrict__ partial, int splits, int tiles, int tiles_q,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // float4 index: tile, row in tile, column quad
+    const int tile = idx >> 14, rt = (idx >> 6) & 255, c4 = idx & 63;
+    if (tile >= tiles) return;
+    const float* src = partial + (int64_t)tile * 65536 + rt * 256 + c4 * 4;
+    float4 a = *(const float4*)src;
+    for (int s = 1; s < splits; ++s) {
+        const float4 v = *(const float4*)(src + (int64_t)s * tiles * 65536);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float* o = out + (int64_t)((tile / tiles_q) * 256 + rt) * ldo + (tile % tiles_q) * 256 + c4 * 4;
+    float4 cur = *(const float4*)o;
+    cur.x += a.x; cur.y += a.y; cur.z += a.z; cur.w += a.w;
+    *(float4*)o = cur;
 }
 
 // column sums: grid (ceil(N/256) , row_splits); each thread owns one column, strides rows
@@ -1218,8 +1249,11 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     }
 }
 
+// room for the partial tiles of the largest 256^2 wgrad launch (~one workgroup per CU, DCLIP_TN256_BLOCKS, plus rounding)
+extern "C" size_t dclip_gemm_tn_workspace_bytes(void) { return (size_t)384 * 65536 * sizeof(float); }
+
 extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t ldo,
-                                 int64_t M, int64_t P, int64_t Q, int splits, void* stream) {
+                                 int64_t M, int64_t P, int64_t Q, int splits, void* workspace, size_t ws_bytes, void* stream) {
     DCLIP_REQUIRE(A && B && dW, "dclip_gemm_tn_acc: null operand");
     DCLIP_REQUIRE(M > 0 && P > 0 && Q > 0, "dclip_gemm_tn_acc: empty problem");
     DCLIP_REQUIRE(P % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
@@ -1228,7 +1262,7 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     DCLIP_REQUIRE(splits >= 1, "dclip_gemm_tn_acc: splits must be >= 1");
     GemmTN p;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.out = dW; p.ldo = ldo;
-    p.M = (int)M; p.P = (int)P; p.Q = (int)Q; p.stamps = g_gemm_stamps;
+    p.M = (int)M; p.P = (int)P; p.Q = (int)Q; p.stamps = g_gemm_stamps; p.partial = nullptr;
     p.tiles_p = (int)((P + TP - 1) / TP); p.tiles_q = (int)((Q + TQ - 1) / TQ);
     int chunk = (int)((M + splits - 1) / splits);
     chunk = ((chunk + TC - 1) / TC) * TC;
@@ -1252,7 +1286,14 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
         q.chunk = ch;
         q.splits = (int)((M + ch - 1) / ch);
         TraceScope tr2(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream, (int)M, (int)P, (int)Q, 256);
+        static const int tn_partial = [] { const char* e = getenv("DCLIP_TN_PARTIAL"); return e ? atoi(e) : 1; }();
+        const size_t need = (size_t)tiles * q.splits * 65536 * sizeof(float);
+        const bool part = tn_partial != 0 && workspace && ws_bytes >= need && ldo % 4 == 0 && ((uintptr_t)dW % 16) == 0 && q.splits > 1;
+        q.partial = part ? (float*)workspace : nullptr;
         hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 8 * HT, (hipStream_t)stream, q);
+        if (part)
+            hipLaunchKernelGGL(tn256_reduce_kernel, dim3((unsigned)(tiles * 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                               q.splits, tiles, q.tiles_q, dW, ldo);
         return dclip_check_launch("dclip_gemm_tn_acc");
     }
     TraceScope tr(DCLIP_TRACE_GEMM_TN, 2.0 * (double)M * (double)P * (double)Q, 2.0 * ((double)M * P + (double)M * Q) + 4.0 * (double)P * Q, stream, (int)M, (int)P, (int)Q, 128);

@@ -40,14 +40,27 @@ def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=No
     return out
 
 
-def gemm_tn_acc(a, b, dw, splits=4):
-    """dw[P,Q] (f32) += a[M,P]^T @ b[M,Q]."""
+_TN_WS = {}
+
+
+def _tn_workspace(device):
+    ws = _TN_WS.get(device)
+    if ws is None:
+        ws = _TN_WS[device] = torch.empty(lib().dclip_gemm_tn_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
+def gemm_tn_acc(a, b, dw, splits=4, workspace=True):
+    """dw[P,Q] (f32) += a[M,P]^T @ b[M,Q].  workspace=True: large outputs leave as per-split partial tiles + a fixed-order sum
+    (no f32 atomics, run-to-run identical); False: f32 atomics."""
     _chk(a, b, dw)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and dw.dtype == torch.float32
     M, P = a.shape
     Q = b.shape[1]
     assert b.shape[0] == M and tuple(dw.shape) == (P, Q) and dw.stride(1) == 1
-    lib().dclip_gemm_tn_acc(_p(a), a.stride(0), _p(b), b.stride(0), _p(dw), dw.stride(0), M, P, Q, splits, _stream())
+    ws = _tn_workspace(a.device) if workspace else None
+    lib().dclip_gemm_tn_acc(_p(a), a.stride(0), _p(b), b.stride(0), _p(dw), dw.stride(0), M, P, Q, splits, _p(ws),
+                            0 if ws is None else ws.numel(), _stream())
     return dw
 
 

@@ -62,8 +62,12 @@ int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
  *   A bf16 [M,P] (lda), B bf16 [M,Q] (ldb).  P % 16 == 0, Q % 16 == 0.  Accumulates with f32 atomics
  *   (weight-shared layers add R uses per step, weight_share_model.py:199-218); `splits` >= 1 partitions M.
  */
+/* workspace (nullable; dclip_gemm_tn_workspace_bytes() bytes, 16-byte aligned): with it the 256 x 256 wgrad pipeline writes each
+ * split's partial tile with plain stores and a second launch adds the splits to dW in a fixed order (no f32 atomics: faster,
+ * and run-to-run identical); without it, or for outputs on the small-tile kernels, f32 atomics as before. */
+size_t dclip_gemm_tn_workspace_bytes(void);
 int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t ldo,
-                      int64_t M, int64_t P, int64_t Q, int splits, void* stream);
+                      int64_t M, int64_t P, int64_t Q, int splits, void* workspace, size_t ws_bytes, void* stream);
 
 /* db[N] (f32) += column sums of X[M,N] (bf16, ld) — bias gradient of nn.Linear. */
 int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N, void* stream);

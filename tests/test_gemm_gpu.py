@@ -116,9 +116,17 @@ def test_gemm_tn_256_pipeline(M, P, Q):
     ops.gemm_tn_acc(a, b, dw, 4)
     ref = 0.5 + a.float().t() @ b.float()
     _close(dw, ref, 1e-5 * M ** 0.5 + 1e-5)
-    # a second, independent accumulation must add exactly one more product (no lost / duplicated atomics)
+    # a second, independent accumulation must add exactly one more product (no lost / duplicated contributions)
     ops.gemm_tn_acc(a, b, dw, 4)
     _close(dw, 2 * ref - 0.5, 1e-5 * M ** 0.5 + 1e-5)
+    # partial tiles + fixed-order sum: run-to-run IDENTICAL gradients (the atomic path is only equal up to f32 summation order)
+    d1, d2 = torch.zeros(P, Q, device='cuda'), torch.zeros(P, Q, device='cuda')
+    ops.gemm_tn_acc(a, b, d1, 4)
+    ops.gemm_tn_acc(a, b, d2, 4)
+    assert torch.equal(d1, d2)
+    d3 = torch.zeros(P, Q, device='cuda')
+    ops.gemm_tn_acc(a, b, d3, 4, workspace=False)                  # the f32-atomic epilogue of the same kernel
+    _close(d3, d1, 1e-5 * M ** 0.5 + 1e-5)
 
 
 def test_gemm_tn_asymmetric():

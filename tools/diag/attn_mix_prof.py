@@ -8,6 +8,23 @@ from distillclip_amd.ops import _p, _stream
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 which = sys.argv[2] if len(sys.argv) > 2 else 'all'
+if which == 'teacher':
+    from distillclip_amd import ops
+    for B, N, H, hd, causal in [(512, 50, 12, 64, False), (512, 77, 8, 64, True)]:
+        D = H * hd
+        qkv = (torch.randn(B * N, 3 * D) * 0.7).bfloat16().cuda()
+        fn = lambda: ops.attn_fused_fwd(qkv, B, N, H, hd, causal)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        print(f'teacher fused attention B {B} N {N} H {H} hd {hd} causal {causal}: {a.elapsed_time(b) / reps * 1e3:8.1f} us (incl. output alloc)', flush=True)
+    sys.exit(0)
 shapes = [(512, 50, 24, 32)] * (which in ('all', 'img')) + [(512, 77, 12, 64)] * (which in ('all', 'txt'))
 for B, N, H, hd in shapes:
     D = H * hd
