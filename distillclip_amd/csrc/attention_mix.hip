@@ -51,7 +51,9 @@ DEVFN void lds_wait_frags(bf16x8 (&f)[GF]) {
 // the value lives in an AGPR from here on (MFMA B operands may be AGPRs; VGPRs stay free for what the VALU touches)
 DEVFN void pin_acc(bf16x8& v) { asm volatile("" : "+a"(v)); }
 DEVFN unsigned long long clock() { return __builtin_readcyclecounter(); }
-DEVFN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }    // no instruction moves across this point
+// no instruction moves across this point.  Required, not a tuning knob: the hand-placed ds_read / s_waitcnt pairs around the ring
+// are only ordered against the MFMAs that consume them by these fences (a build without them fails test_kernels_gpu).
+DEVFN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // LDS-DMA: 16 bytes per lane from the lane's own global address to (wave-uniform dst) + lane * 16; completion is tracked by vmcnt
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
