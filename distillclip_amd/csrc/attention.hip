@@ -32,9 +32,9 @@ struct AttnMM {
 
 // 8 consecutive columns j0 .. j0 + 7 (j0 % 8 == 0) of row i of a score-like matrix of one (b, h): row-major rows of Np, or the
 // quad-blocked layout of the register-resident score stage (element (i, j) at ((j >> 2) * N + i) * 4 + (j & 3)): two 8-byte halves
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ u32x4 load_a8(const bf16_t* A, int64_t lda, int N, int blocked, int i, int j0) {
     if (!blocked) return *(const u32x4*)(A + (int64_t)i * lda + j0);
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     const u32x2 lo = *(const u32x2*)(A + ((int64_t)(j0 >> 2) * N + i) * 4);
     const u32x2 hi = *(const u32x2*)(A + ((int64_t)((j0 >> 2) + 1) * N + i) * 4);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -151,6 +151,38 @@ __device__ __forceinline__ void wave_stage(const bf16_t* __restrict__ G, int64_t
     }
 }
 
+// wave_stage with the columns permuted in groups of four: group q = DT * g + dt of a row lands at group 4 * dt + g.  A transposing
+// fragment read of column block dt then hands MFMA row 4 g + r the column (4 DT) g + 4 dt + r, so that in a product computed
+// transposed (O^T = V^T P^T) lane (query c, group g) ends up with the 4 DT CONSECUTIVE output columns (4 DT) g .. + 4 DT - 1 of its
+// query: 16- / 32-byte row-contiguous stores instead of 8-byte pieces on 64 different lines per instruction.
+template <int ROWB, int DT>
+__device__ __forceinline__ void wave_stage_perm4(const bf16_t* __restrict__ G, int64_t ld, int rows_valid, int rows, char* tile, int lane) {
+    constexpr int cpr = DT * 2;                // 16-byte chunks per row (HD = 16 DT)
+    constexpr int BATCH = 8;                   // loads in flight per lane: a load -> write loop pays one HBM round trip per chunk
+    const int total = rows * cpr;
+    for (int base = 0; base < total; base += BATCH * 64) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int idx = base + k * 64 + lane;
+            const int r = idx / cpr, c = idx - r * cpr;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < total && r < rows_valid) v[k] = *(const u32x4*)(G + (int64_t)r * ld + c * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int idx = base + k * 64 + lane;
+            const int r = idx / cpr, c = idx - r * cpr;
+            const int q0 = 2 * c, q1 = 2 * c + 1;
+            const int p0 = 4 * (q0 % DT) + q0 / DT, p1 = 4 * (q1 % DT) + q1 / DT;
+            if (idx < total) {
+                *(u32x2*)(tile + r * ROWB + p0 * 8) = u32x2{v[k][0], v[k][1]};
+                *(u32x2*)(tile + r * ROWB + p1 * 8) = u32x2{v[k][2], v[k][3]};
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // NN: C[(b,i), h*HD + d] = alpha * sum_j A[b,h,i,j] * B[(b,j), h*HD + d]
 // ---------------------------------------------------------------------------------------------------------
@@ -167,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
     const int b = prob / p.H, h = prob % p.H;
     const int n32 = (p.N + 31) & ~31;
     char* tile = smem + wave * (n32 * ROWB);        // sized by the padded sequence, not by NMAX: N = 50 fits 6 workgroups per CU instead of 3
-    wave_stage<ROWB>(p.Bm + (int64_t)b * p.N * p.ldb + h * HD, p.ldb, 0, p.N, n32, HD, tile, lane);
+    wave_stage_perm4<ROWB, HD / 16>(p.Bm + (int64_t)b * p.N * p.ldb + h * HD, p.ldb, p.N, n32, tile, lane);
     __syncthreads();
     const bf16_t* A = (const bf16_t*)p.A + ((int64_t)b * p.H + h) * p.N * p.lda;
     const int nt = (p.N + 15) >> 4, nks = n32 >> 5;
@@ -194,20 +226,20 @@ __global__ __launch_bounds__(256) void attn_nn_kernel(AttnMM p) {
             if (ks < nks) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
+                    // computed transposed (C^T = B^T A^T; both fragment kinds share one lane layout, so the operands just swap)
                     const bf16x8 bf = tr_frag<ROWB>(tile, ks * 32, d * 16, lane);
-                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc[d], 0, 0, 0);
+                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[ks], acc[d], 0, 0, 0);
                 }
             }
         }
-        if (live) {
-            bf16_t* C = (bf16_t*)p.C + (int64_t)b * p.N * p.ldc + h * HD;
+        const int i = it * 16 + fr;
+        if (live && i < p.N) {
+            // lane (query fr, group g) holds the 4 DT consecutive columns from (4 DT) g (wave_stage_perm4): 16-byte row-contiguous stores
+            bf16_t* o = (bf16_t*)p.C + ((int64_t)b * p.N + i) * p.ldc + h * HD + (lane >> 4) * (4 * DT);
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = it * 16 + (lane >> 4) * 4 + r;
-                    if (i < p.N) C[(int64_t)i * p.ldc + d * 16 + fr] = f2bf(acc[d][r] * p.alpha);
-                }
+            for (int d = 0; d < DT; d += 2)
+                *(bf16x8*)(o + d * 4) = bf16x8{f2bf(acc[d][0] * p.alpha), f2bf(acc[d][1] * p.alpha), f2bf(acc[d][2] * p.alpha), f2bf(acc[d][3] * p.alpha),
+                                                f2bf(acc[d + 1][0] * p.alpha), f2bf(acc[d + 1][1] * p.alpha), f2bf(acc[d + 1][2] * p.alpha), f2bf(acc[d + 1][3] * p.alpha)};
         }
 #pragma unroll
         for (int ks = 0; ks < KSM; ++ks) af[ks] = afn[ks];
@@ -229,10 +261,12 @@ struct AttnFused {
     float scale;
 };
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
+// NTM = 16-key tiles the instance holds registers for (4: N <= 64, 5: N <= 80, 8: N <= 128); the K fragments and score tiles scale
+// with it, and at NTM = 4 / 5 three waves per SIMD fit where the N = 128 sizing allowed two
+template <int HD, int NTM>
+__global__ __launch_bounds__(256, NTM <= 5 ? 3 : 2) void attn_fused_fwd_kernel(AttnFused p) {
     constexpr int VROWB = HD * 2 + 32;
-    constexpr int KS = HD / 32, DT = HD / 16, NTM = NMAX / 16, KSM = NMAX / 32;
+    constexpr int KS = HD / 32, DT = HD / 16, KSM = (NTM + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nprob = p.B * p.H;
@@ -247,8 +281,6 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
     const bf16_t* Q = p.qkv + (int64_t)b * p.N * p.ldq + h * HD;
     const bf16_t* K = Q + D;
     const bf16_t* V = Q + 2 * D;
-    wave_stage<VROWB>(V, p.ldq, 0, p.N, n32, HD, vt, lane);
-    for (int idx = lane; idx < 16 * prowb / 4; idx += 64) ((unsigned*)pt)[idx] = 0u;
     const int fr = lane & 15, g = lane >> 4, fk = g * 8;
     bf16x8 kf[NTM][KS];
 #pragma unroll
@@ -264,6 +296,9 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Q + (int64_t)ia * p.ldq + ks * 32 + fk);
     }
+    // V last: its loads join the K / Q requests already in flight, and only its LDS writes wait
+    wave_stage_perm4<VROWB, DT>(V, p.ldq, p.N, n32, vt, lane);
+    for (int idx = lane; idx < 16 * prowb / 4; idx += 64) ((unsigned*)pt)[idx] = 0u;
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         if (it + 1 < nt) {
@@ -333,9 +368,12 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
             }
         __builtin_amdgcn_wave_barrier();
         if (live && i < p.N) {
-            bf16_t* o = p.ctx + ((int64_t)b * p.N + i) * p.ldc + h * HD + g * 4;
+            // (columns permuted when V was staged: this lane holds the 4 DT consecutive columns from (4 DT) g of query i)
+            bf16_t* o = p.ctx + ((int64_t)b * p.N + i) * p.ldc + h * HD + g * (4 * DT);
 #pragma unroll
-            for (int d = 0; d < DT; ++d) *(bf16x4*)(o + d * 16) = bf16x4{f2bf(oc[d][0]), f2bf(oc[d][1]), f2bf(oc[d][2]), f2bf(oc[d][3])};
+            for (int d = 0; d < DT; d += 2)
+                *(bf16x8*)(o + d * 4) = bf16x8{f2bf(oc[d][0]), f2bf(oc[d][1]), f2bf(oc[d][2]), f2bf(oc[d][3]),
+                                                f2bf(oc[d + 1][0]), f2bf(oc[d + 1][1]), f2bf(oc[d + 1][2]), f2bf(oc[d + 1][3])};
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -345,22 +383,23 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(AttnFused p) {
 // ---------------------------------------------------------------------------------------------------------
 // TN: C[(b,j), h*HD + d] = alpha * sum_i A[b,h,i,j] * B[(b,i), h*HD + d]   (contraction over query rows)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int TN_MAXJ = NMAX / 16;             // 8 output row tiles
-constexpr int TN_AROW = NMAX * 2 + 32;         // 288 B rows for the A chunk [32 x Np]
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
+// MAXJ = output row tiles (16 rows each) the instance holds accumulators for: 4 (N <= 64), 5 (N <= 80) or 8 (N <= 128)
+template <int HD, int MAXJ>
+__global__ __launch_bounds__(256, MAXJ <= 5 ? 2 : 1) void attn_tn_kernel(AttnMM p) {
     constexpr int BROW = HD * 2 + 32;
     constexpr int DT = HD / 16;
-    constexpr int ACH = 32 * (NMAX / 8) / 64, BCH = 32 * (HD / 8) / 64;     // 16-byte chunks per lane of a 32-row chunk
+    constexpr int TN_MAXJ = MAXJ;
+    constexpr int AROW = MAXJ * 32 + 32;            // LDS row of the A chunk [32 x 16 MAXJ] bf16, padded
+    constexpr int ACH = 32 * (MAXJ * 2) / 64, BCH = 32 * (HD / 8) / 64;     // 16-byte chunks per lane of a 32-row chunk (A: Np <= 16 MAXJ columns)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nprob = p.B * p.H;
     const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
     const bool live = blockIdx.x * 4 + wave < nprob;
     const int b = prob / p.H, h = prob % p.H;
-    char* at = smem + wave * (32 * TN_AROW + 32 * BROW);
-    char* bt = at + 32 * TN_AROW;
+    char* at = smem + wave * (32 * AROW + 32 * BROW);
+    char* bt = at + 32 * AROW;
     const bf16_t* A = (const bf16_t*)p.A + ((int64_t)b * p.H + h) * p.N * p.lda;
     const bf16_t* Bm = p.Bm + (int64_t)b * p.N * p.ldb + h * HD;
     const int ntj = (p.N + 15) >> 4;
@@ -377,9 +416,13 @@ __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
     auto load_chunk = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < ACH; ++k) {
-            const int idx = k * 64 + lane, r = idx / acpr, c = idx - r * acpr;
+            // lane -> (row r, 16-byte column chunk c): columns fastest for row-major A, ROWS fastest for the quad-blocked layout, whose
+            // 8-byte pieces of consecutive rows are adjacent in memory (16 lanes = 128 contiguous bytes; with the columns fastest every
+            // lane of a load touched a line of its own and the texture addresser, not HBM, set the kernel's time)
+            const int idx = k * 64 + lane;
+            const int r = p.a_blocked ? (idx & 31) : idx / acpr, c = p.a_blocked ? (idx >> 5) : idx - r * acpr;
             ra[k] = u32x4{0u, 0u, 0u, 0u};
-            if (r < 32 && ch * 32 + r < p.N) ra[k] = load_a8(A, p.lda, p.N, p.a_blocked, ch * 32 + r, c * 8);
+            if (r < 32 && c < acpr && ch * 32 + r < p.N) ra[k] = load_a8(A, p.lda, p.N, p.a_blocked, ch * 32 + r, c * 8);
         }
 #pragma unroll
         for (int k = 0; k < BCH; ++k) {
@@ -391,13 +434,18 @@ __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
     auto store_chunk = [&]() {
 #pragma unroll
         for (int k = 0; k < ACH; ++k) {
-            const int idx = k * 64 + lane, r = idx / acpr, c = idx - r * acpr;
-            if (r < 32) *(u32x4*)(at + r * TN_AROW + c * 16) = ra[k];
+            const int idx = k * 64 + lane;
+            const int r = p.a_blocked ? (idx & 31) : idx / acpr, c = p.a_blocked ? (idx >> 5) : idx - r * acpr;
+            if (r < 32 && c < acpr) *(u32x4*)(at + r * AROW + c * 16) = ra[k];
         }
 #pragma unroll
         for (int k = 0; k < BCH; ++k) {
+            // columns permuted in groups of four as in wave_stage_perm4: the product is computed transposed and a lane ends up with
+            // 4 DT consecutive output columns
             const int idx = k * 64 + lane, r = idx / (HD / 8), c = idx % (HD / 8);
-            *(u32x4*)(bt + r * BROW + c * 16) = rb[k];
+            const int q0 = 2 * c, q1 = 2 * c + 1;
+            *(u32x2*)(bt + r * BROW + (4 * (q0 % DT) + q0 / DT) * 8) = u32x2{rb[k][0], rb[k][1]};
+            *(u32x2*)(bt + r * BROW + (4 * (q1 % DT) + q1 / DT) * 8) = u32x2{rb[k][2], rb[k][3]};
         }
     };
     load_chunk(0);
@@ -414,25 +462,27 @@ __global__ __launch_bounds__(256) void attn_tn_kernel(AttnMM p) {
         for (int j = 0; j < TN_MAXJ; ++j) {
             if (j < ntj) {
                 // columns beyond Np were never staged: they only feed output rows >= N, which are not stored
-                const bf16x8 af = tr_frag<TN_AROW>(at, 0, j * 16, lane);
+                const bf16x8 af = tr_frag<AROW>(at, 0, j * 16, lane);
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
-                    acc[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[d], acc[j][d], 0, 0, 0);
+                    acc[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[d], af, acc[j][d], 0, 0, 0);      // transposed: lane = output row
             }
         }
     }
     if (live) {
-        bf16_t* C = (bf16_t*)p.C + (int64_t)b * p.N * p.ldc + h * HD;
+        bf16_t* C = (bf16_t*)p.C + (int64_t)b * p.N * p.ldc + h * HD + (lane >> 4) * (4 * DT);
 #pragma unroll
         for (int j = 0; j < TN_MAXJ; ++j)
-            if (j < ntj)
+            if (j < ntj) {
+                const int jj = j * 16 + (lane & 15);
+                if (jj < p.N) {
+                    bf16_t* o = C + (int64_t)jj * p.ldc;
 #pragma unroll
-                for (int d = 0; d < DT; ++d)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int jj = j * 16 + (lane >> 4) * 4 + r;
-                        if (jj < p.N) C[(int64_t)jj * p.ldc + d * 16 + (lane & 15)] = f2bf(acc[j][d][r] * p.alpha);
-                    }
+                    for (int d = 0; d < DT; d += 2)
+                        *(bf16x8*)(o + d * 4) = bf16x8{f2bf(acc[j][d][0] * p.alpha), f2bf(acc[j][d][1] * p.alpha), f2bf(acc[j][d][2] * p.alpha), f2bf(acc[j][d][3] * p.alpha),
+                                                        f2bf(acc[j][d + 1][0] * p.alpha), f2bf(acc[j][d + 1][1] * p.alpha), f2bf(acc[j][d + 1][2] * p.alpha), f2bf(acc[j][d + 1][3] * p.alpha)};
+                }
+            }
     }
 }
 
@@ -1187,6 +1237,7 @@ extern "C" int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C
                              int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream) {
     AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha, a_blocked};
     if (int rc = check_mm(p, "dclip_attn_nn")) return rc;
+    DCLIP_REQUIRE(ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ldb % 8 == 0 && ((uintptr_t)Bm % 16) == 0, "dclip_attn_nn: token-major operands must be 16-byte aligned");
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 2);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
@@ -1200,11 +1251,17 @@ extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C
                              int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream) {
     AttnMM p{A, Np, (const bf16_t*)Bm, ldb, C, ldc, (int)B, (int)H, (int)N, (int)Np, (int)hd, alpha, a_blocked};
     if (int rc = check_mm(p, "dclip_attn_tn")) return rc;
+    DCLIP_REQUIRE(ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ldb % 8 == 0 && ((uintptr_t)Bm % 16) == 0, "dclip_attn_tn: token-major operands must be 16-byte aligned");
     TraceScope tr(DCLIP_TRACE_ATTN, 2.0 * B * H * N * N * hd, 4.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 3);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 32) hipLaunchKernelGGL((attn_tn_kernel<32>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (32 * 2 + 32)), st, p);
-    else hipLaunchKernelGGL((attn_tn_kernel<64>), grid, dim3(256), 4 * (32 * TN_AROW + 32 * (64 * 2 + 32)), st, p);
+    const int ntile = ((int)Np + 15) / 16;
+    const int mj = ntile <= 4 ? 4 : (ntile <= 5 ? 5 : 8);
+    const size_t lds = (size_t)4 * (32 * (mj * 32 + 32) + 32 * ((int)hd * 2 + 32));
+#define TN_LAUNCH(HDv, NTv) hipLaunchKernelGGL((attn_tn_kernel<HDv, NTv>), grid, dim3(256), lds, st, p)
+    if (hd == 32) { if (ntile <= 4) TN_LAUNCH(32, 4); else if (ntile <= 5) TN_LAUNCH(32, 5); else TN_LAUNCH(32, 8); }
+    else { if (ntile <= 4) TN_LAUNCH(64, 4); else if (ntile <= 5) TN_LAUNCH(64, 5); else TN_LAUNCH(64, 8); }
+#undef TN_LAUNCH
     return dclip_check_launch("dclip_attn_tn");
 }
 
@@ -1212,15 +1269,18 @@ extern "C" int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int
                                     float scale, int causal, void* stream) {
     DCLIP_REQUIRE(qkv && ctx && B > 0 && H > 0 && N > 0 && N <= NMAX, "dclip_attn_fused_fwd: bad argument (N <= %d)", NMAX);
     DCLIP_REQUIRE(hd == 32 || hd == 64, "dclip_attn_fused_fwd: head dim must be 32 or 64 (got %ld)", (long)hd);
-    DCLIP_REQUIRE(ldq % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 8) == 0, "dclip_attn_fused_fwd: misaligned buffers");
+    DCLIP_REQUIRE(ldq % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "dclip_attn_fused_fwd: misaligned buffers");
     AttnFused p{(const bf16_t*)qkv, ldq, (bf16_t*)ctx, ldc, (int)B, (int)H, (int)N, causal, scale};
     TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd, 8.0 * B * H * N * hd, stream, (int)(B * H), (int)N, (int)hd, 4);
     const dim3 grid((unsigned)((B * H + 3) / 4));
     const int n32 = ((int)N + 31) & ~31;
     const size_t lds = (size_t)4 * (n32 * (hd * 2 + 32) + 16 * (n32 * 2 + 16));
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 32) hipLaunchKernelGGL((attn_fused_fwd_kernel<32>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((attn_fused_fwd_kernel<64>), grid, dim3(256), lds, st, p);
+    const int ntile = ((int)N + 15) / 16;
+#define FUSED_LAUNCH(HDv, NTv) hipLaunchKernelGGL((attn_fused_fwd_kernel<HDv, NTv>), grid, dim3(256), lds, st, p)
+    if (hd == 32) { if (ntile <= 4) FUSED_LAUNCH(32, 4); else if (ntile <= 5) FUSED_LAUNCH(32, 5); else FUSED_LAUNCH(32, 8); }
+    else { if (ntile <= 4) FUSED_LAUNCH(64, 4); else if (ntile <= 5) FUSED_LAUNCH(64, 5); else FUSED_LAUNCH(64, 8); }
+#undef FUSED_LAUNCH
     return dclip_check_launch("dclip_attn_fused_fwd");
 }
 
