@@ -279,7 +279,10 @@ __device__ __forceinline__ void stage_rowhalf(const bf16_t* __restrict__ G, int6
     const int r = X >> 6, c = (X >> 4) & 3;
     constexpr int AROWS = RH * 32;
     {
-        const int g = wave / RH, i = wave % RH + dn * RH;          // row block `wave` of 2 RH
+        // RH = 3: six row blocks for eight waves — waves 6, 7 repeat blocks 0, 1 (same bytes to the same LDS address), so every
+        // wave issues the same number of LDS-DMA instructions and the counted vmcnt waits stay wave-independent
+        const int wv = RH == 3 ? wave % 6 : wave;
+        const int g = wv / RH, i = wv % RH + dn * RH;              // row block `wv` of 2 RH
         int row = m0 + g * AROWS + i * 16 + r;
         row = row < rows_max ? row : rows_max - 1;
         const bf16_t* src = G + (int64_t)row * ld + k0 + c * 8;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     stamp(0);
     // LDS-DMA instructions per wave: B half 2, A row-half 2 (RH = 4) or 3 (RH = 5).  vmcnt completes in issue order, so "wait
     // until half-tile X has landed" = vmcnt(number of instructions issued after X)
-#define WAIT_VM2(n8, n10) do { if (MI == 8) WAIT_VMCNT(n8); else WAIT_VMCNT(n10); } while (0)
+#define WAIT_VM2(n8, n10) do { if (MI == 10) WAIT_VMCNT(n10); else WAIT_VMCNT(n8); } while (0)
     const int npro = nload < 7 ? nload : 7;                // tile 0 entirely, tile 1: B_lo, B_hi, A_up
     for (int l = 0; l < npro; ++l) issue(l);
     if (nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);    // B_lo, B_hi, A_up of tile 0 landed (younger: A_dn(0), B, B, A_up(1))
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // once per batch boundary: none at all where the side operands of the whole tile fit the registers the dead fragments free.
     constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
     constexpr int NU = 2 * MI;
-    constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : 5)) : (MI == 8 ? 16 : 10));
+    constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : (MI == 6 ? 6 : 5))) : (MI == 10 ? 10 : NU));
     static_assert(NU % BU == 0, "batch size must divide the unit count");
     EpiSide side[SIDE ? BU : 1];
     const int row0 = m0 + wr * AROWS + rl;
@@ -1149,23 +1152,30 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
                 tm = tm1;
             }
         }
-        // tile height: 256 or 320 rows, whichever needs fewer rounds x rows on 256 CUs (a tie keeps the 256-row tile, whose
-        // loads carry no duplicates); DCLIP_GEMM320=0 disables the 320-row variant, =2 forces it
+        // tile height: 192, 256 or 320 rows (MI = 6, 8, 10), whichever needs the fewest rounds x cycles per tile on 256 CUs (a tie keeps
+        // the 256-row tile, whose loads carry no duplicates); DCLIP_GEMM320=0 keeps 256 rows, =2 forces 320, =6 forces 192
         static const int mode320 = [] { const char* e = getenv("DCLIP_GEMM320"); return e ? atoi(e) : 1; }();
-        bool tall = false;
+        int mi = 8;
         // (every epilogue variant fits the 160 accumulator registers of the 320-row tile without spilling: tools/diag/regs.py)
-        constexpr bool TALL_OK = true;
-        if (TALL_OK && mode320 && !has_rest) {
-            const int tm10 = (p.M + 319) / 320;
+        if (mode320 && !has_rest) {
             // rounds on 256 CUs x cycles per tile, from the in-kernel stamps (tools/diag/gemm_phases.py): prologue 3.3 k, main
             // loop 2 750 (256 rows) / 3 200 (320 rows) cycles per k-tile — the taller tile does 1.25 x the work in 1.16 x the
-            // time — and an epilogue that scales with the rows (bf16 ~9.5 k, f32 + residual ~40 k when the whole chip stores)
+            // time; the 192-row tile (M = 12 800 problems, where 320 x 256 tiles leave half the CUs idle at N = 768) is priced at
+            // 0.78 x — and an epilogue that scales with the rows (bf16 ~9.5 k, f32 + residual ~40 k when the whole chip stores)
             static const double tall_bias = [] { const char* e = getenv("DCLIP_GEMM320_BIAS"); return e ? atof(e) : 1.0; }();
             const double nkt = (double)(p.K / BK), e8 = out_f32 ? 40000.0 : (ACT == 0 || ACT == 4 ? 9500.0 : 14000.0);
-            const double c8 = (double)((tm * tn + 255) / 256) * (3300.0 + nkt * 2750.0 + e8);
-            const double c10 = (double)((tm10 * tn + 255) / 256) * (3300.0 + nkt * 3200.0 + 1.25 * e8);
-            tall = mode320 == 2 || c10 * tall_bias < c8;
-            if (tall) tm = tm10;
+            auto cost = [&](int rows, double per_kt, double escale) {
+                const int tmx = (p.M + rows - 1) / rows;
+                return (double)((tmx * tn + 255) / 256) * (3300.0 + nkt * per_kt + escale * e8);
+            };
+            const double c8 = cost(256, 2750.0, 1.0), c10 = cost(320, 3200.0, 1.25) * tall_bias, c6 = cost(192, 2150.0, 0.75);
+            if (mode320 == 2) mi = 10;
+            else if (mode320 == 6) mi = 6;
+            else {
+                if (c10 < c8) mi = 10;
+                if (c6 < (mi == 10 ? c10 : c8) * 0.97) mi = 6;
+            }
+            tm = (p.M + mi * 32 - 1) / (mi * 32);
         }
         p.tiles_m = tm; p.tiles_n = tn;
         const int grid256 = p.tiles_m * p.tiles_n;
@@ -1184,13 +1194,17 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
             }
             p.group_n = force_g > 0 ? force_g : best_g;
         }
-        if constexpr (TALL_OK) {
-            if (tall) {
-                const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2);
-                if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
-                else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
-                return dclip_check_launch("dclip_gemm_nt");
-            }
+        if (mi == 10) {
+            const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2);
+            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
+            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
+            return dclip_check_launch("dclip_gemm_nt");
+        }
+        if (mi == 6) {
+            const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2);
+            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 6>), dim3(grid256), dim3(512), lds192, st, p);
+            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6>), dim3(grid256), dim3(512), lds192, st, p);
+            return dclip_check_launch("dclip_gemm_nt");
         }
         const size_t lds256 = 8 * HT;
         if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 8>), dim3(grid256), dim3(512), lds256, st, p);

@@ -227,9 +227,11 @@ def test_gemm_nt_row_split_between_tile_sizes(M, N, K):
     _close(x, ref + bias + res, 1e-4)
 
 
-@pytest.mark.parametrize('M,N,K', [(25600, 768, 128), (25610, 768, 64), (39424, 512, 192), (20480, 1024, 64), (25600, 768, 768)])
+@pytest.mark.parametrize('M,N,K', [(25600, 768, 128), (25610, 768, 64), (39424, 512, 192), (20480, 1024, 64), (25600, 768, 768),
+                                   (12800, 768, 768), (12810, 768, 128), (12800, 768, 3072)])
 def test_gemm_nt_320_row_tile_variant(M, N, K):
-    """Shapes whose 256^2 tiling leaves a nearly empty last round on 256 CUs ([25600, 768] = 300 tiles, [39424, 512] = 308) run on
+    """(The M = 12 800 cases — image.yaml at B = 256 — run on the 192 x 256 tile: 201 workgroups instead of 120 of 320 rows.)
+    Shapes whose 256^2 tiling leaves a nearly empty last round on 256 CUs ([25600, 768] = 300 tiles, [39424, 512] = 308) run on
     320 x 256 tiles (240 / 248 workgroups, one round): full and ragged last row tile, every epilogue the towers use with it
     (bias, f32 + residual, in-place residual, QuickGELU / GELU + saved pre-activation, positional row table, column sums), and
     bit-identical repeats (LDS-DMA races show as run-to-run differences)."""
@@ -264,7 +266,7 @@ def test_gemm_nt_320_row_tile_variant(M, N, K):
         _close(o.view(M // G, G, N), ref.view(M // G, G, N) + pos, 1e-4)
 
 
-@pytest.mark.parametrize('M,N,K', [(4096, 3072, 768), (25600, 2312, 128), (2100, 520, 192), (39424, 3072, 64)])
+@pytest.mark.parametrize('M,N,K', [(4096, 3072, 768), (25600, 2312, 128), (2100, 520, 192), (39424, 3072, 64), (12800, 768, 192)])
 def test_gemm_nt_register_epilogue_variants(M, N, K):
     """The 256- / 320-row kernels store straight from the accumulators (operand-swapped MFMA, permuted B staging): every epilogue
     variant with bf16 output, including the column sums reduced by lane shuffles (the dgrad GEMMs' bias gradients), on shapes that
