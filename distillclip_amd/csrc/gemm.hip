@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -319,18 +320,23 @@ __device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int64_t o, i
     if (ACT == 3 || ACT == 4) sd.z = *(const bf16x8*)(p.aux_in + o);
 }
 
-template <int ACT, bool OUT_F32>
+// MODE 0: every optional operand is a run-time test (wave-uniform branches: four per 8-column unit, 80 per 320 x 256 tile and wave —
+// about 40 % of the issue slots of a plain bf16 epilogue, which is issue-bound).  MODE 1 / 2: the launch has no positional table, no
+// residual and no saved pre-activation (ACT 5 always saves its derivative), without / with bias-gradient column sums — the
+// combinations the step's bf16 GEMMs use; the tests are compiled out.
+template <int ACT, bool OUT_F32, int MODE = 0>
 __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, int64_t o, int64_t orr,
                                               const float (&bias)[8], float (&csum)[8], const EpiSide& sd) {
+    constexpr bool LEAN = MODE != 0;            // MODE 3: f32 output with the (in-place) residual, nothing else optional
     // o = row * ldc + col, orr = row * ldr + col (formed incrementally by the caller)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
-    if (p.row_group > 0) {      // (patch-embedding GEMM only: the position-embedding rows, L2-resident)
+    if (!LEAN && p.row_group > 0) {      // (patch-embedding GEMM only: the position-embedding rows, L2-resident)
         const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
         const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
     }
-    if (ACT != 5 && p.aux_out) {
+    if (!LEAN && ACT != 5 && p.aux_out) {
         bf16x8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
@@ -362,9 +368,9 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
             gelu_erf_both_f(v[e], g, dg);
             v[e] = g; dz[e] = f2bf(dg);
         }
-        if (p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
+        if (LEAN || p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
     }
-    if (p.residual) {
+    if (MODE == 3 || (!LEAN && p.residual)) {
         float4 r0, r1;
         if (OUT_F32) { r0 = sd.r0; r1 = sd.r1; }
         else {
@@ -383,7 +389,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
         for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
         *(bf16x8*)((bf16_t*)p.C + o) = ov;
     }
-    if (!OUT_F32 && p.colsum) {
+    if (!OUT_F32 && (MODE == 2 || (MODE == 0 && p.colsum))) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
     }
@@ -568,28 +574,48 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     const int row0 = m0 + wr * AROWS + rl;
     const int64_t o0 = (int64_t)row0 * p.ldc + colb, r0off = (int64_t)row0 * p.ldr + colb;
     const int64_t ostep = 16 * p.ldc, rstep = 16 * p.ldr;
+    // full: the tile lies inside the matrix (all but the last row / column of tiles) — the per-unit bounds test is then one scalar
+    // branch instead of two vector compares and an exec-mask update.  (Compiled out entirely, the 2 MI units become one basic block
+    // whose addresses and conversions are all hoisted to the top: 100-240 spilled registers.)
+    const bool full = m0 + BMT <= p.M && n0 + 256 <= p.N;
+    auto run_units = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-    for (int ub = 0; ub < NU; ub += BU) {
-        if (SIDE) {
+        for (int ub = 0; ub < NU; ub += BU) {
+            if (SIDE) {
+#pragma unroll
+                for (int u = ub; u < ub + BU; ++u) {
+                    const int i = u >> 1, jp = u & 1;
+                    if (full || (row0 + i * 16 < p.M && colb + jp * 32 < p.N))
+                        epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
+                }
+            }
 #pragma unroll
             for (int u = ub; u < ub + BU; ++u) {
                 const int i = u >> 1, jp = u & 1;
-                if (row0 + i * 16 < p.M && colb + jp * 32 < p.N)
-                    epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
+                const int row = row0 + i * 16, col = colb + jp * 32;
+                if (full || (row < p.M && col < p.N)) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                    epilogue_vec8<ACT, OUT_F32, MODE>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                                                      side[SIDE ? u - ub : 0]);
+                }
             }
         }
-#pragma unroll
-        for (int u = ub; u < ub + BU; ++u) {
-            const int i = u >> 1, jp = u & 1;
-            const int row = row0 + i * 16, col = colb + jp * 32;
-            if (row < p.M && col < p.N) {
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-                epilogue_vec8<ACT, OUT_F32>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
-                                            side[SIDE ? u - ub : 0]);
-            }
-        }
+    };
+    // (kernel arguments: the tests below are scalar, the whole workgroup takes one path)
+    const bool lean = p.row_group == 0 && (ACT == 5 ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT_F32 ? p.residual != nullptr : p.residual == nullptr);
+    if constexpr (OUT_F32) {
+        if (lean) run_units(std::integral_constant<int, 3>{});
+        else run_units(std::integral_constant<int, 0>{});
+    } else if constexpr (ACT == 3 || ACT == 4) {      // (the dgrad epilogues always come with bias-gradient column sums in the step)
+        if (lean && p.colsum) run_units(std::integral_constant<int, 2>{});
+        else run_units(std::integral_constant<int, 0>{});
+    } else {
+        if (lean && !p.colsum) run_units(std::integral_constant<int, 1>{});
+        else if (lean) run_units(std::integral_constant<int, 2>{});
+        else run_units(std::integral_constant<int, 0>{});
     }
     if (!OUT_F32 && p.colsum) {     // (f32 output + column sums: launch_nt routes that combination to the 128^2 kernel)
         // 16-lane shuffle reduce, then the 8 waves combine through LDS (idle since the main loop's last barrier) so that the
