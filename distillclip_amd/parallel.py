@@ -217,15 +217,26 @@ class GradSync:
     def note_token_ids(self, tw, ids):
         """Forward time, text student with a plain (uncompressed) embedding table: the gradient of the [V, D] table is non-zero only
         in the rows of the token ids of the GLOBAL batch.  The ranks exchange their ids ([B, 77] int32 each), every rank builds
-        the same sorted union with static shapes (sort, first-occurrence flags, prefix sum: no host synchronisation) and the row
-        count travels to pinned host memory; by the time the embedding bucket is released at the end of the backward it has
-        long arrived, and the collective over the compacted rows can be sized on the host."""
+        the same sorted union with static shapes (sort, first-occurrence flags, prefix sum: no host synchronisation), counts the
+        union rows that fall into each rank's shard of the bucket, and those W counts travel to pinned host memory; by the time
+        the embedding bucket is released at the end of the backward they have long arrived, and the collective over the compacted
+        rows can be sized on the host."""
         spec = tw.sparse_spec() if hasattr(tw, 'sparse_spec') else None
         if spec is None or not (self.enabled and self.sharded and self.sparse_embedding) or tw.dp is None:
             return
         bucket, t0, V, D = spec
-        if tw.dp.buckets[bucket] is None:
+        bk = tw.dp.buckets[bucket]
+        if bk is None:
             return
+        b0, b1 = bk[0], bk[1]
+        per = (b1 - b0) // self.world
+        # table rows [r_lo, r_hi) that intersect rank k's shard [b0 + k per, b0 + (k + 1) per) — a shard boundary may cut a row, which
+        # then belongs to both neighbours' segments
+        t1 = t0 + V * D
+        seg = []
+        for k in range(self.world):
+            lo, hi = max(b0 + k * per, t0), min(b0 + (k + 1) * per, t1)
+            seg.append((0, 0) if lo >= hi else ((lo - t0) // D, (hi - t0 + D - 1) // D))
         loc = ids.reshape(-1).to(torch.int32)
         s = self.stream_for(loc, tw)
         if s is not None:
@@ -238,45 +249,64 @@ class GradSync:
             first = torch.ones_like(srt, dtype=torch.bool)
             first[1:] = srt[1:] != srt[:-1]
             pos = torch.cumsum(first.to(torch.int64), 0) - 1
-            uniq = torch.full((min(V, self.world * n),), V - 1, dtype=torch.int64, device=loc.device)
+            uniq = torch.full((min(V, self.world * n),), V, dtype=torch.int64, device=loc.device)     # V = "no row" (sorts last)
             uniq.scatter_(0, pos, srt)                   # duplicates write the same value to the same slot
-            count = (pos[-1:] + 1).to(torch.int64)
+            bounds = torch.tensor([x for lo_hi in seg for x in lo_hi], dtype=torch.int64, device=loc.device)
+            cuts = torch.searchsorted(uniq, bounds)      # [2 W]: first union index >= r_lo / >= r_hi of every segment
             if loc.is_cuda:
-                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
-                host.copy_(count, non_blocking=True)
+                host = torch.empty(2 * self.world, dtype=torch.int64, pin_memory=True)
+                host.copy_(cuts, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(s)
             else:
-                host, ev = count.clone(), None
-        tw._sparse = dict(bucket=bucket, t0=t0, V=V, D=D, uniq=uniq, count=host, event=ev)
+                host, ev = cuts.clone(), None
+        tw._sparse = dict(bucket=bucket, t0=t0, V=V, D=D, uniq=uniq, cuts=host, cuts_dev=cuts, event=ev)
 
     def _release_sparse(self, tw, b, sp):
-        """(on the tower's exchange stream) average the touched table rows over the ranks, write this rank's shard of the bucket
-        (zeros in the untouched rows, bit-identical to the dense reduce-scatter in the touched ones), clear the touched rows"""
+        """(on the tower's exchange stream) a reduce-scatter over the TOUCHED table rows only: every rank contributes, per destination
+        rank, the union rows of that rank's shard (segments padded to the longest one, so the collective has equal parts), receives
+        the average of its own segment and writes it into its shard (zeros in the untouched rows), then clears the touched rows.
+        Bytes on the wire: (W - 1) / W x W x longest segment x D x 4 ~ (W - 1) / W x touched rows x D x 4, never more than the dense
+        reduce-scatter of V rows."""
         b0, b1, o0, o1, off, _ = b
         if sp['event'] is not None:
             sp['event'].synchronize()                   # recorded at forward time: done long ago
-        n = int(sp['count'].item())
+        cuts = [int(x) for x in sp['cuts'].tolist()]
+        W, rank = self.world, self.rank
+        starts, counts = cuts[0::2], [cuts[2 * k + 1] - cuts[2 * k] for k in range(W)]
         t0, V, D = sp['t0'], sp['V'], sp['D']
         t1 = t0 + V * D
         g = tw.flat_grad
         grp = self.group_for(tw)
         shard = tw.gshard[off:off + (o1 - o0)]
         shard.zero_()
-        rows = sp['uniq'][:n]
+        uniq = sp['uniq']
         table = g[t0:t1].view(V, D)
-        compact = table.index_select(0, rows)            # [n, D]
-        all_reduce_avg(compact, group=grp)
+        mseg = max(max(counts), 1)
+        ar = torch.arange(mseg, device=uniq.device)
+        # (segment starts / counts come from the device copy of the cuts: a host list -> device tensor here would be a synchronous
+        #  copy in stream order, i.e. the host would wait for the backward that this stream waits for)
+        cd = sp['cuts_dev'].view(W, 2)
+        st = cd[:, 0:1]
+        ct = cd[:, 1:2] - cd[:, 0:1]
+        valid = ar.unsqueeze(0) < ct                                             # [W, mseg]
+        idx = (st + ar.unsqueeze(0)).clamp_(max=uniq.numel() - 1)
+        rows_all = torch.where(valid, uniq[idx], torch.zeros_like(idx))          # padding reads row 0 and is masked to zero
+        send = table.index_select(0, rows_all.reshape(-1)).view(W, mseg, D) * valid.unsqueeze(2).to(table.dtype)
+        recv = torch.empty((mseg, D), dtype=table.dtype, device=table.device)
+        reduce_scatter_avg(recv.view(-1), send.view(-1), group=grp)
         # owned part of the table: flat [lo, hi) -> rows [r_lo, r_hi) (the shard boundary may cut a row)
         lo, hi = max(o0, t0), min(o1, t1)
-        if lo < hi:
+        n_own = counts[rank]
+        if lo < hi and n_own > 0:
             r_lo, r_hi = (lo - t0) // D, (hi - t0 + D - 1) // D
-            inside = ((rows >= r_lo) & (rows < r_hi)).to(compact.dtype).unsqueeze(1)
-            buf = torch.zeros((r_hi - r_lo, D), dtype=compact.dtype, device=compact.device)
-            buf.index_add_(0, (rows - r_lo).clamp_(0, r_hi - r_lo - 1), compact * inside)     # rows outside add 0 to a clamped slot
+            rows = rows_all[rank, :n_own]
+            buf = torch.zeros((r_hi - r_lo, D), dtype=table.dtype, device=table.device)
+            buf.index_copy_(0, rows - r_lo, recv[:n_own])
             start = lo - (t0 + r_lo * D)
             shard[lo - o0:hi - o0].copy_(buf.view(-1)[start:start + (hi - lo)])
-        table.index_fill_(0, rows, 0.0)                  # the backward accumulates (+=): touched rows clean for the next step
+        touched = uniq[:max(cuts)]                       # the union (the segments cover every table row of the bucket)
+        table.index_fill_(0, touched, 0.0)               # the backward accumulates (+=): touched rows clean for the next step
         # the rest of the bucket (positional embedding, ...) is small and dense
         for a, e in ((b0, t0), (t1, b1)):
             if a < e:
@@ -286,7 +316,8 @@ class GradSync:
                 if x0 < x1:
                     shard[x0 - o0:x1 - o0].copy_(g[x0:x1])
                 rest.zero_()
-        tw.sparse_rows_last = n                         # (diagnostics / tests: rows exchanged instead of V)
+        tw.sparse_rows_last = int(touched.numel())       # (diagnostics / tests: rows exchanged instead of V)
+        tw.sparse_segment_rows_last = mseg               # rows per destination rank in the padded collective
 
     def finish(self, tw):
         """after the backward call: release whatever the callbacks did not (a backward without per-bucket callbacks)"""
