@@ -36,7 +36,13 @@ def family(n):
 
 out = os.path.join(ROOT, 'profiles')
 os.makedirs(out, exist_ok=True)
-stats = glob.glob(os.path.join(ROOT, f'gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv'))[0]
+def newest(pattern):
+    """gpurun merges every call's outputs into the same directory: take the latest run's file"""
+    fs = sorted(glob.glob(os.path.join(ROOT, pattern)), key=os.path.getmtime)
+    return fs[-1:]
+
+
+stats = newest(f'gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv')[0]
 shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
@@ -48,7 +54,7 @@ for r in rows:
 
 traffic = {}
 for which, mult in (('fetch', 2.0), ('write', 1.0)):
-    fs = glob.glob(os.path.join(ROOT, f'gpurun_out/prof_{tag}_{which}/*/*_counter_collection.csv'))
+    fs = newest(f'gpurun_out/prof_{tag}_{which}/*/*_counter_collection.csv')
     if not fs:
         continue
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -65,7 +71,7 @@ json.dump(traffic, open(os.path.join(out, f'{tag}_traffic.json'), 'w'), indent=1
 
 # MFMA utilisation per family: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)
 mfma = {}
-fs = glob.glob(os.path.join(ROOT, f'gpurun_out/prof_{tag}_mfma/*/*_counter_collection.csv'))
+fs = newest(f'gpurun_out/prof_{tag}_mfma/*/*_counter_collection.csv')
 if fs:
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(fs[0])):
