@@ -142,18 +142,25 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(wl, seed, budget_s=40.0):
-    """The oracle (CPU fp32 restatement of the reference, pinned by reference-run goldens) timed on this host: same model, same
-    step contents (fwd, loss, zero_grad, backward, AdamW).  BASELINE.md §2: B in {4, 32}, thread sweep, 1 warm-up then best of
-    >= 3 steps; bounded to ~budget_s of CPU work (configurations are tried most-promising first and the sweep stops when the
-    budget is spent).  Reports the best (batch, threads)."""
+def cpu_step_factory(wl, seed):
+    """-> make_step(B): one oracle training step (fwd, loss, zero_grad, backward, AdamW) of the workload on the CPU, built from
+    the same YAML values as the HIP model (tests/test_bench_cpu.py runs one step of every workload at B = 2)"""
     import torch
     import oracle
     from distillclip_amd import synth
-    ncpu = effective_cpus()
     kind = wl['kind']
     res = wl['res']
-    cfg_i = dict(S_IMG, img_size=res)
+    # the same YAML values the HIP model is built from (tests/golden/yaml_init_args.json)
+    ia = YAML_ARGS[wl['yaml']]['model']['init_args']
+    enc = lambda key: {k: v for k, v in ia[key]['init_args'].items() if v is not None}
+    if kind == 'dual':
+        cfg_i, tcfg = dict(enc('image_student'), img_size=res), enc('text_student')
+    else:
+        cfg_i = dict(enc('student_encoder'), img_size=res) if kind == 'image' else None
+        tcfg = enc('student_encoder') if kind == 'text' else None
+    heads_i = (cfg_i or {}).get('num_heads', 24)
+    heads_t = (tcfg or {}).get('num_heads', 12)
+    loss_para = dict(ia['loss_control_para'])
     sd_i = sd_t = None
     params = []
     tsd_i = T(synth.teacher_image_state(seed, resolution=res)) if kind != 'text' else None
@@ -166,37 +173,48 @@ def cpu_baseline(wl, seed, budget_s=40.0):
             sd_i['pos_embed'] = tsd_i['visual.positional_embedding'].unsqueeze(0).clone()
         params += [v for v in sd_i.values() if v.requires_grad]
     if kind != 'image':
-        tcfg = S_TXT if kind == 'dual' else S_TXT_C
         sd_t = {k: v.requires_grad_(True) for k, v in T(synth.student_text_state(seed, **tcfg)).items()}
         params += list(sd_t.values())
-    lr, wd = (1e-4, 1e-3) if kind == 'dual' else (5e-3, 1e-2)
+    lr, wd = ia['lr'], ia['weight_decay']
     opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
-    lc = oracle.LossOracle(**(LOSS_DUAL if kind == 'dual' else LOSS_ONE))
+    lc = oracle.LossOracle(**loss_para)
 
     def make_step(B):
         image, text, _ = make_inputs(wl, seed, B)
 
         def step():
             if kind == 'dual':
-                so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, 24), oracle.student_text_forward(sd_t, text, 12))
+                so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, heads_i), oracle.student_text_forward(sd_t, text, heads_t))
                 with torch.no_grad():
                     to = oracle.clip_forward(oracle.teacher_image_forward(tsd_i, image), oracle.teacher_text_forward(tsd_t, text))
                 loss, _ = lc(so, to, 'all')
             elif kind == 'image':
-                so = oracle.student_image_forward(sd_i, image, 24)
+                so = oracle.student_image_forward(sd_i, image, heads_i)
                 with torch.no_grad():
                     to = oracle.teacher_image_forward(tsd_i, image)
                 loss, _ = lc(so, to, 'image')
             else:
-                so = oracle.student_text_forward(sd_t, text, 12)
+                so = oracle.student_text_forward(sd_t, text, heads_t)
                 with torch.no_grad():
                     to = oracle.teacher_text_forward(tsd_t, text)
                 loss, _ = lc(so, to, 'text')
             opt.zero_grad()
             loss.backward()
             opt.step()
+            return float(loss.detach())
         return step
 
+    return make_step
+
+
+def cpu_baseline(wl, seed, budget_s=40.0):
+    """The oracle (CPU fp32 restatement of the reference, pinned by reference-run goldens) timed on this host: same model, same
+    step contents (fwd, loss, zero_grad, backward, AdamW).  BASELINE.md §2: B in {4, 32}, thread sweep, 1 warm-up then best of
+    >= 3 steps; bounded to ~budget_s of CPU work (configurations are tried most-promising first and the sweep stops when the
+    budget is spent).  Reports the best (batch, threads)."""
+    import torch
+    ncpu = effective_cpus()
+    make_step = cpu_step_factory(wl, seed)
     threads = sorted({max(1, ncpu // 4), max(1, ncpu // 2), ncpu}, reverse=True)
     plan = [(32, t) for t in threads] + [(4, t) for t in reversed(threads)]
     t_start = time.perf_counter()

@@ -388,3 +388,19 @@ def test_teacher_text_prefix_is_exact():
         from distillclip_amd.model.component import RepeatTextTransformer
         s = RepeatTextTransformer(depth=4, repeated_times=2, use_transform=True).cuda()
         s._tower.forward(text, training=False, tokens_eff=40)
+
+
+def test_unfused_score_stage_path_matches_the_same_goldens():
+    """The default student path is the register-resident score stage (attention_mix.hip).  The unfused kernels of rounds 1-2
+    (attn_nt + softmax, scores through HBM) remain as the fallback for head counts dclip_attn_mix_supported rejects and behind
+    DCLIP_ATTN_MIX=0; the knob is read once per process, so the forward / training-step / backward golden tests of this file
+    are re-run in ONE child process with it set (the parent keeps no GPU work in flight meanwhile)."""
+    import subprocess
+    import sys
+    torch.cuda.synchronize()
+    env = dict(os.environ, DCLIP_ATTN_MIX='0')
+    sel = 'tiny_forward_vs_reference_golden or tiny_dual_training_step or tiny_backward_vs_rounding_matched or real_shapes_b4'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', sel, '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-2000:]
