@@ -1,6 +1,7 @@
 // HBM-bound helper kernels around the GEMMs: dtype casts / weight transposes, im2row for the patch embedding,
 // token-embedding gather / scatter-add, positional / class-token tables and their gradients, EOT pick indices.
 #include "common.h"
+#include <limits.h>
 
 namespace {
 
@@ -143,13 +144,27 @@ __global__ void token_table_bwd_kernel(const float* __restrict__ ts, float* __re
 // out[n,:] += sum_b G[b,n,:]   grid (ceil(D/256), N, bsplit)
 __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ G, float* __restrict__ out, int B, int N,
                                                         int D, int per) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // 16-byte loads, four samples in flight per trip (D % 4 == 0: checked by the caller)
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= D) return;
     const int n = blockIdx.y;
     const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
-    float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += G[((int64_t)b * N + n) * D + c];
-    unsafeAtomicAdd(out + (int64_t)n * D + c, s);
+    const int64_t bs = (int64_t)N * D;
+    const float* g = G + (int64_t)n * D + c;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        const float4 v0 = *(const float4*)(g + b * bs), v1 = *(const float4*)(g + (b + 1) * bs);
+        const float4 v2 = *(const float4*)(g + (b + 2) * bs), v3 = *(const float4*)(g + (b + 3) * bs);
+        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; b < b1; ++b) {
+        const float4 v = *(const float4*)(g + b * bs);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* o = out + (int64_t)n * D + c;
+    unsafeAtomicAdd(o, s.x); unsafeAtomicAdd(o + 1, s.y); unsafeAtomicAdd(o + 2, s.z); unsafeAtomicAdd(o + 3, s.w);
 }
 
 template <bool OUT_F32>
@@ -210,20 +225,31 @@ __global__ __launch_bounds__(256) void embed_hot_kernel(const int64_t* __restric
     if (s2) unsafeAtomicAdd(dtable + h2 * D + c, a2);
 }
 
-// idx[b] = b*N + argmax_n ids[b,n] (first maximum, like torch.argmax) ; ids == null -> b*N (class-token row)
-__global__ void pick_index_kernel(const int64_t* __restrict__ ids, int id_stride, int* __restrict__ idx, int B, int N) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+// idx[b] = b*N + argmax_n ids[b,n] (first maximum, like torch.argmax) ; ids == null -> b*N (class-token row).
+// One wave per caption (a thread per caption walked its 77 ids as a dependent load chain: 19 us for 512 captions).
+__global__ __launch_bounds__(256) void pick_index_kernel(const int64_t* __restrict__ ids, int id_stride, int* __restrict__ idx, int B, int N) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     int best = 0;
     if (ids) {
-        int64_t m = ids[(int64_t)b * id_stride];
-        for (int n = 1; n < id_stride; ++n) {          // argmax over the FULL caption (reference text_encoder.py:86)
-            const int64_t v = ids[(int64_t)b * id_stride + n];
-            if (v > m) { m = v; best = n; }
+        // per-lane first maximum over n = lane, lane + 64, ... (argmax over the FULL caption, reference text_encoder.py:86), then the
+        // wave's: larger value wins, equal values the smaller position
+        long long m = LLONG_MIN;
+        int pos = INT_MAX;
+        for (int n = lane; n < id_stride; n += 64) {
+            const long long v = ids[(int64_t)b * id_stride + n];
+            if (v > m) { m = v; pos = n; }
         }
-        best = best < N ? best : N - 1;               // contract: the EOT lies inside the processed prefix
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long om = __shfl_xor(m, o);
+            const int op = __shfl_xor(pos, o);
+            if (om > m || (om == m && op < pos)) { m = om; pos = op; }
+        }
+        best = pos < N ? pos : N - 1;                 // contract: the EOT lies inside the processed prefix
     }
-    idx[b] = b * N + best;
+    if (lane == 0) idx[b] = b * N + best;
 }
 
 // out[r, :] = src[idx[r], :]   (f32 rows)
@@ -379,9 +405,9 @@ extern "C" int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* d
 }
 
 extern "C" int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_t D, void* stream) {
-    DCLIP_REQUIRE(G && out && B > 0 && N > 0 && D > 0, "dclip_batch_sum_acc: bad argument");
+    DCLIP_REQUIRE(G && out && B > 0 && N > 0 && D > 0 && D % 4 == 0 && ((uintptr_t)G % 16) == 0, "dclip_batch_sum_acc: bad argument (D % 4 == 0, 16-byte aligned rows)");
     const int per = 32;
-    dim3 grid((unsigned)((D + 255) / 256), (unsigned)N, (unsigned)((B + per - 1) / per));
+    dim3 grid((unsigned)((D / 4 + 255) / 256), (unsigned)N, (unsigned)((B + per - 1) / per));
     hipLaunchKernelGGL(batch_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, out, (int)B, (int)N, (int)D, per);
     return dclip_check_launch("dclip_batch_sum_acc");
 }
@@ -415,7 +441,7 @@ extern "C" int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int d
 
 extern "C" int dclip_pick_index(const int64_t* ids, int64_t id_stride, int32_t* idx, int64_t B, int64_t N, void* stream) {
     DCLIP_REQUIRE(idx && B > 0 && N > 0 && id_stride >= N, "dclip_pick_index: bad argument");
-    hipLaunchKernelGGL(pick_index_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, idx, (int)B, (int)N);
+    hipLaunchKernelGGL(pick_index_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, idx, (int)B, (int)N);
     return dclip_check_launch("dclip_pick_index");
 }
 
