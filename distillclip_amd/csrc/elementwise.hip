@@ -192,13 +192,30 @@ template <bool IN_F32>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const void* __restrict__ dx,
                                                             float* __restrict__ dtable, int rows, int D, int64_t h0, int64_t h1,
                                                             int64_t h2) {
-    const int64_t total = (int64_t)rows * D;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / D), c = (int)(i % D);
+    // one wave per token row: the id is read once, rows of the three hot ids (two thirds of a caption batch is padding) leave at
+    // once (an element-per-thread grid paid a 64-bit division and an id load per element, also for the rows it then skipped)
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
         const int64_t id = ids[r];
         if (id == h0 || id == h1 || id == h2) continue;
-        const float v = IN_F32 ? ((const float*)dx)[i] : bf2f(((const bf16_t*)dx)[i]);
-        unsafeAtomicAdd(dtable + id * D + c, v);
+        float* dst = dtable + id * D;
+        // a lane per column, columns lane, lane + 64, ...: every atomic instruction covers 256 contiguous bytes (atomics retire per
+        // instruction and per line touched: 16-byte loads with four strided atomics per lane took twice as long); loads first
+        constexpr int CH = 4;
+        for (int c0 = lane; c0 < D; c0 += 64 * CH) {
+            float v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int c = c0 + 64 * u;
+                v[u] = c < D ? (IN_F32 ? ((const float*)dx)[(int64_t)r * D + c] : bf2f(((const bf16_t*)dx)[(int64_t)r * D + c])) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < D) unsafeAtomicAdd(dst + c, v[u]);
+            }
+        }
     }
 }
 
@@ -211,15 +228,30 @@ __global__ __launch_bounds__(256) void embed_hot_kernel(const int64_t* __restric
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     bool s0 = false, s1 = false, s2 = false;
-    for (int r = r0; r < r1; ++r) {
-        const int64_t id = ids[r];                       // wave-uniform
+    const bool live = c < D;
+    auto val = [&](int r) { return live ? (IN_F32 ? ((const float*)dx)[(int64_t)r * D + c] : bf2f(((const bf16_t*)dx)[(int64_t)r * D + c])) : 0.f; };
+    // four rows per trip with unconditional loads (the ids are wave-uniform: the selects below cost nothing, the loads overlap)
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        int64_t id[4]; float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { id[u] = ids[r + u]; v[u] = val(r + u); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (id[u] == h0) { a0 += v[u]; s0 = true; }
+            else if (id[u] == h1) { a1 += v[u]; s1 = true; }
+            else if (id[u] == h2) { a2 += v[u]; s2 = true; }
+        }
+    }
+    for (; r < r1; ++r) {
+        const int64_t id = ids[r];
         if (id != h0 && id != h1 && id != h2) continue;
-        const float v = c < D ? (IN_F32 ? ((const float*)dx)[(int64_t)r * D + c] : bf2f(((const bf16_t*)dx)[(int64_t)r * D + c])) : 0.f;
+        const float v = val(r);
         if (id == h0) { a0 += v; s0 = true; }
         else if (id == h1) { a1 += v; s1 = true; }
         else { a2 += v; s2 = true; }
     }
-    if (c >= D) return;
+    if (!live) return;
     if (s0) unsafeAtomicAdd(dtable + h0 * D + c, a0);
     if (s1) unsafeAtomicAdd(dtable + h1 * D + c, a1);
     if (s2) unsafeAtomicAdd(dtable + h2 * D + c, a2);
@@ -424,7 +456,7 @@ extern "C" int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const f
 extern "C" int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
                                        int64_t vocab, void* stream) {
     DCLIP_REQUIRE(ids && dx && dtable && rows > 0 && D > 0 && vocab >= 3, "dclip_embed_scatter_add: bad argument");
-    const dim3 grid(grid_for(rows * D));
+    const dim3 grid((unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096));
     const int64_t h0 = 0, h1 = vocab - 2, h2 = vocab - 1;       // padding, SOT, EOT (reference data/component/ms_coco.py:37)
     const int rpb = 128;
     const dim3 hgrid((unsigned)((D + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
