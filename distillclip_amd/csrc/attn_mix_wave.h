@@ -310,6 +310,7 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
 #pragma unroll
                     for (int k = 0; k < 4; ++k) m[t][k] = r == 0 ? a[k] : fmaxf(m[t][k], a[k]);
                 }
+                hw::keep_alive(pk);              // (MFMA operands built by the VALU outlive their MFMAs: hw::keep_alive)
             }
         }
 #pragma unroll
@@ -330,11 +331,12 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
         f32x4 av[4][RT], mx[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) mx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x8 pk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f16x8 pk = pack_s<C, f16x8>(sa, r);
+            pk[r] = pack_s<C, f16x8>(sa, r);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) av[r][t] = hw::mfma_f16(w.wl[t], pk, -m[t]);      // log2-domain score minus the reference
+            for (int t = 0; t < RT; ++t) av[r][t] = hw::mfma_f16(w.wl[t], pk[r], -m[t]);   // log2-domain score minus the reference
         }
         hw::sched_fence();
 #pragma unroll
@@ -369,6 +371,7 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) l[t][k] += hw::exp2(av[r][t][k]);
+        hw::keep_alive(pk);
         if (st) t_i += hw::clock() - tq;
     };
     const int nqf = N >> 2;                          // quads that lie entirely below N
@@ -419,11 +422,12 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
         // stage-wise over the quad's four keys: 4 x RT independent MFMAs, then 4 x RT x 4 exponentials, ... (the chains of the four
         // keys are independent: issued round-robin they hide each other's MFMA / transcendental latency)
         f32x4 a[4][RT];
+        f16x8 pk[4], pp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f16x8 pk = pack_s<C, f16x8>(sa, r);
+            pk[r] = pack_s<C, f16x8>(sa, r);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) a[r][t] = hw::mfma_f16(w.wl[t], pk, nlse[t]);
+            for (int t = 0; t < RT; ++t) a[r][t] = hw::mfma_f16(w.wl[t], pk[r], nlse[t]);
         }
         hw::sched_fence();
 #pragma unroll
@@ -432,14 +436,15 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(a[r][t][k]) : 0.f;
+        hw::keep_alive(pk);
         hw::sched_fence();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f16x8 pp = pack_a<C, f16x8>(a[r]);
+            pp[r] = pack_a<C, f16x8>(a[r]);
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                a[r][t] = hw::mfma_f16(w.ww[t], pp, z);
+                a[r][t] = hw::mfma_f16(w.ww[t], pp[r], z);
             }
         }
         hw::sched_fence();
@@ -447,6 +452,7 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) rp[t][k] = bf16x4{(bf16_t)a[0][t][k], (bf16_t)a[1][t][k], (bf16_t)a[2][t][k], (bf16_t)a[3][t][k]};
+        hw::keep_alive(pp);
         if (st) t_i += hw::clock() - tq;
     };
     for (int u = 0; u < nqf; ++u) quad2(std::false_type{}, u);
@@ -539,7 +545,10 @@ DEVFN void wg_product(const char* tx, const char* ty, int lane, f32x4 (&acc)[C::
         for (int t = 0; t < C::RT; ++t)
 #pragma unroll
             for (int u = 0; u < C::RT; ++u) acc[t][u] = hw::mfma_bf16(xa[t], yb[u], acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < C::RT; ++t) { hw::keep_alive(xa[t]); hw::keep_alive(yb[t]); }
     }
+    if (C::RT > 1) hw::mfma_src_guard();     // 2 x RT^2 MFMAs in a row: the last fragments must survive the queue
 }
 
 // One (sample, 16-query tile) of backward pass A (PASS_B = false): delta_h[i] = sum_j P_h dP_h -> p.delta, dW_w += dR P^T;
@@ -608,15 +617,17 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
         kv.done();
         if (st) { const unsigned long long t = hw::clock(); t_s += t - tq; tq = t; }
         // stage-wise over the quad's four keys, as the forward
+        f16x8 pk[4];
+        bf16x8 dk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f16x8 pk = pack_s<C, f16x8>(sa, r);
-            const bf16x8 dk = pack_s<C, bf16x8>(dra, r);
+            pk[r] = pack_s<C, f16x8>(sa, r);
+            dk[r] = pack_s<C, bf16x8>(dra, r);
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                pr[r][t] = hw::mfma_f16(w.wl[t], pk, nlse[t]);
-                dp[r][t] = hw::mfma_bf16(w.wwt[t], dk, z);     // dP = conv_w^T(dR)
+                pr[r][t] = hw::mfma_f16(w.wl[t], pk[r], nlse[t]);
+                dp[r][t] = hw::mfma_bf16(w.wwt[t], dk[r], z);  // dP = conv_w^T(dR)
             }
         }
         hw::sched_fence();
@@ -626,6 +637,8 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pr[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(pr[r][t][k]) : 0.f;     // keys beyond N: P = 0
+        hw::keep_alive(pk);                          // (MFMA operands built by the VALU outlive their MFMAs: hw::keep_alive)
+        hw::keep_alive(dk);
         if (!PASS_B) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -648,16 +661,17 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
                     for (int k = 0; k < 4; ++k) dp[r][t][k] = pr[r][t][k] * (dp[r][t][k] - delta[t][k]);     // dA
             hw::sched_fence();
             // dS = conv_l^T(dA), two keys at a time (their packed pair is half of the 8-byte store)
+            bf16x8 da[4];
 #pragma unroll
             for (int r2 = 0; r2 < 4; r2 += 2) {
                 f32x4 ds[2][RT];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const bf16x8 da = pack_a<C, bf16x8>(dp[r2 + e]);
+                    da[r2 + e] = pack_a<C, bf16x8>(dp[r2 + e]);
 #pragma unroll
                     for (int t = 0; t < RT; ++t) {
                         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        ds[e][t] = hw::mfma_bf16(w.wlt[t], da, z);
+                        ds[e][t] = hw::mfma_bf16(w.wlt[t], da[r2 + e], z);
                     }
                 }
 #pragma unroll
@@ -671,6 +685,7 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             wg_store_a<C>(tx, lane, dp);
             wg_store_s<C>(ty, lane, sa, p.scale);
             hw::lds_fence();
+            hw::keep_alive(da);                      // the four mix MFMAs above queue up: their operands stay put until here
         }
         if (st) t_w += hw::clock() - tq;
     };

@@ -1,5 +1,6 @@
 """GPU parity of the LayerNorm / embedding / attention kernels against torch fp32 on identical (bf16-rounded) inputs."""
 import math
+import os
 
 import pytest
 import torch
@@ -208,7 +209,8 @@ def test_fused_student_attention_forward(B, N, H, hd):
 
 
 @pytest.mark.parametrize('B,N,H,hd', [(3, 77, 12, 64), (2, 17, 4, 32), (3, 13, 2, 64), (2, 50, 12, 32), (1, 101, 8, 64), (5, 16, 4, 64),
-                                      (2, 128, 12, 64), (1, 1, 2, 64), (3, 50, 24, 32), (2, 101, 24, 32), (9, 77, 12, 64), (70, 50, 24, 32)])
+                                      (2, 128, 12, 64), (1, 1, 2, 64), (3, 50, 24, 32), (2, 101, 24, 32), (9, 77, 12, 64), (70, 50, 24, 32),
+                                      (2, 16, 8, 32), (5, 31, 8, 32), (7, 127, 8, 32), (3, 50, 12, 32), (2, 33, 4, 64)])
 def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
     """dclip_attn_mix_fwd / _bwd (attention_mix.hip; reference weight_share_model.py:101-125): S, A, P, dR live only in registers
     and both head mixes run on the matrix pipe (f16 operands in the forward -- the precision the reference's fp16 autocast gives
@@ -274,6 +276,19 @@ def test_register_resident_mixed_attention_fwd_bwd(B, N, H, hd):
     _close(dww, 2 * wwr.grad, 2e-2, 'dWw accumulates')
     R2, lse2 = ops.attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale)
     assert torch.equal(ops.unblock_scores(R2), R) and torch.equal(lse2, lse)
+
+
+def test_register_resident_mixed_attention_random_shapes():
+    """60 random (B, N, H, hd) through the score stage against fp32 autograd, run-to-run equality included (tools/diag/mix_fuzz.py).
+    This is the test that found the MFMA-operand hazard of round 3 — an operand register rewritten by the VALU a few instructions
+    after the last of four queued MFMAs, H = 8 / hd = 32 only (attention_mix.hip: hw::keep_alive) — which no fixed shape list had."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.synchronize()
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'diag', 'mix_fuzz.py'), '60', '23'], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_fused_student_attention_support_matrix():

@@ -220,6 +220,9 @@ static inline void pin_acc(bf16x8&) {}
 template <int OFF> static inline bf16x8 lds_read_frag(const char* p) { return *(const bf16x8*)(p + OFF); }
 template <int N, int GF> static inline void lds_wait_frags(bf16x8 (&)[GF]) {}
 static inline unsigned long long clock() { return 0; }
+template <class T8> static inline void keep_alive(const T8 (&)[4]) {}
+template <class T8> static inline void keep_alive(const T8&) {}
+static inline void mfma_src_guard() {}
 static inline void dma16(const void* src, char* dst) { emu::dma16(src, dst); }
 template <int N> static inline void dma_wait() { emu::dma_wait(N); }
 }  // namespace hw
