@@ -1112,18 +1112,20 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_mix_kernel(SoftmaxBwd p)
                     *(bf16_t*)(tD + h * ROWB + (32 * ct + c) * 2) = f2bf(dp[r]);
                 }
                 f32x16 ds = {0};
+                bf16x8 bf[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8 bf;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bf[e] = f2bf(dp[8 * s + e]);
-                    ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf, ds, 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) bf[s][e] = f2bf(dp[8 * s + e]);
+                    ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl[s], bf[s], ds, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     if (h < H) *(bf16_t*)(tR + h * ROWB + (32 * ct + c) * 2) = f2bf(ds[r]);      // this key tile's dR columns are dead
                 }
+                // operands built by the VALU stay live past their (queued) MFMAs: attention_mix.hip, hw::keep_alive
+                asm volatile("" :: "v"(bf[0]), "v"(bf[1]));
             }
         }
         // dW_l += dA S^T
