@@ -310,7 +310,7 @@ DEVFN void fwd_item(const FwdArgs& p, int b, int it, int lane, const FwdWeights<
 #pragma unroll
                     for (int k = 0; k < 4; ++k) m[t][k] = r == 0 ? a[k] : fmaxf(m[t][k], a[k]);
                 }
-                hw::keep_alive(pk);              // (MFMA operands built by the VALU outlive their MFMAs: hw::keep_alive)
+                hw::mfma_src_guard();            // (once per tile: the operand must outlive its MFMAs, see hw::keep_alive)
             }
         }
 #pragma unroll
@@ -548,7 +548,7 @@ DEVFN void wg_product(const char* tx, const char* ty, int lane, f32x4 (&acc)[C::
 #pragma unroll
         for (int t = 0; t < C::RT; ++t) { hw::keep_alive(xa[t]); hw::keep_alive(yb[t]); }
     }
-    if (C::RT > 1) hw::mfma_src_guard();     // 2 x RT^2 MFMAs in a row: the last fragments must survive the queue
+    hw::mfma_src_guard();                    // 2 x RT^2 MFMAs in a row: the last fragments must survive the queue
 }
 
 // One (sample, 16-query tile) of backward pass A (PASS_B = false): delta_h[i] = sum_j P_h dP_h -> p.delta, dW_w += dR P^T;
@@ -637,8 +637,6 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pr[r][t][k] = (!TAIL || j0 + r < N) ? hw::exp2(pr[r][t][k]) : 0.f;     // keys beyond N: P = 0
-        hw::keep_alive(pk);                          // (MFMA operands built by the VALU outlive their MFMAs: hw::keep_alive)
-        hw::keep_alive(dk);
         if (!PASS_B) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -687,6 +685,9 @@ DEVFN void bwd_item(const BwdArgs& p, int b, int it, int lane, const BwdWeights<
             hw::lds_fence();
             hw::keep_alive(da);                      // the four mix MFMAs above queue up: their operands stay put until here
         }
+        // MFMA operands built by the VALU outlive their (queued) MFMAs by at least a dozen issue slots: hw::keep_alive
+        hw::keep_alive(pk);
+        hw::keep_alive(dk);
         if (st) t_w += hw::clock() - tq;
     };
     for (int u = 0; u < nqf; ++u) quad(std::false_type{}, u);
