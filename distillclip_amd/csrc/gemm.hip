@@ -541,6 +541,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
+    // the last MFMAs may still be queued in front of the matrix pipe: a dozen idle slots before the epilogue's VALU can take over
+    // the fragment registers they read (the hazard of attention_mix.hip, hw::keep_alive; once per tile)
+    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
     stamp(2);
 
     // epilogue, straight from registers (see stage_half_perm): lane (g, c) owns row c of every row tile i and, per column pair
@@ -1013,6 +1016,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");      // (as in gemm_nt256_kernel: operands of queued MFMAs)
     stamp(2);
 
     // epilogue: 4 slabs of 64 rows through LDS, then row-contiguous f32 atomics (256 lanes x 4 B = 1 KiB per row)
