@@ -1,5 +1,5 @@
 """random shapes through gemm_nt (all epilogues), the attention products and the teacher's fused attention against torch fp32 on the same
-bf16 inputs, run-to-run equality included: python tools/diag/kernel_fuzz.py [cases] [seed]"""
+bf16 inputs (run-to-run equality included), plus wgrad and LayerNorm forward: python tools/diag/kernel_fuzz.py [cases] [seed]"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -97,5 +97,27 @@ for t in range(cases):
             if not e < 8e-3:
                 bad += 1
                 print('FAIL', name, (B, Nq, H, hd), 'blocked' if src is Ablk else 'row-major', e, flush=True)
+    # ---- wgrad (gemm_tn_acc), LayerNorm forward / backward
+    Mw = rng.choice([1024, 4096, 25600, 51200, 78848, 64 * rng.randrange(16, 900)])
+    P, Q = rng.choice([256, 512, 768, 2304, 3072]), rng.choice([256, 512, 768, 2304, 3072])
+    xa, xb = rnd((Mw, P), 10 * t + 6, 0.5), rnd((Mw, Q), 10 * t + 7, 0.5)
+    want = xa.float().t() @ xb.float()
+    dws = []
+    for _ in range(2):
+        dw = torch.zeros(P, Q, device='cuda')
+        ops.gemm_tn_acc(xa, xb, dw, splits=rng.choice([2, 4, 8]))
+        dws.append(dw)
+    e = rel(dws[0], want)
+    if not e < 2e-4:
+        bad += 1
+        print('FAIL gemm_tn', (Mw, P, Q), e, flush=True)
+    Dl = rng.choice([512, 768])
+    Ml = rng.choice([512, 25600, 39424, rng.randrange(100, 20000)])
+    x = torch.randn(Ml, Dl, device='cuda'); gm = torch.randn(Dl, device='cuda'); bt = torch.randn(Dl, device='cuda')
+    y, mean, rstd = ops.layernorm_fwd(x, gm, bt)
+    yr = torch.nn.functional.layer_norm(x, (Dl,), gm, bt)
+    if not rel(y, yr) < 6e-3:
+        bad += 1
+        print('FAIL ln_fwd', (Ml, Dl), rel(y, yr), flush=True)
 print('cases', cases, 'failed', bad)
 sys.exit(1 if bad else 0)
