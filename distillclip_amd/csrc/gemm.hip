@@ -9,40 +9,17 @@
 // K-tile.  The LDS image is made of 1 KiB [16 rows x 32 k] sub-tiles (one per wave-instruction) with the
 // st_16x32 XOR swizzle (byte ^= ((byte >> 9) & 1) << 5) applied on the SOURCE address and again on the
 // ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
-#include <math.h>
-#include <stdlib.h>
-#include "common.h"
-#include <type_traits>
+
+#include "gemm_common.h"
+
+using namespace dgemm;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int SUB = 1024;                       // bytes of one [16 x 32] bf16 sub-tile
 constexpr int TILE_BYTES = (BM / 16) * (BK / 32) * SUB;   // 16 KiB per operand per stage
 constexpr int CLD = BN + 4;                     // f32 row stride of the C tile staged through LDS in the epilogue
 constexpr int NT_LDS = (4 * TILE_BYTES > BM * CLD * 4) ? 4 * TILE_BYTES : BM * CLD * 4;
 
-struct GemmNT {
-    const bf16_t* A; int64_t lda;
-    const bf16_t* B; int64_t ldb;
-    void* C; int64_t ldc;
-    int M, N, K;
-    float alpha;
-    const float* bias;
-    const bf16_t* aux_in;
-    bf16_t* aux_out;
-    const float* residual; int64_t ldr;
-    int row_group; const float* rowadd;
-    float* colsum;                                  // += column sums of the epilogue output (bias gradient), may be null
-    int tiles_m, tiles_n;
-    unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps): 6 x u64 per workgroup, else null
-    int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
-};
-
-__device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
 
 // one wave stages 4 of the 16 sub-tiles of an operand tile
 __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ G, int64_t ld, int row0, int rows_max,
@@ -301,102 +278,6 @@ __device__ __forceinline__ void stage_rowhalf(const bf16_t* __restrict__ G, int6
     }
 }
 
-// side operands of one output row segment, loaded ahead of use: residual and C may alias (in-place residual stream), so the
-// compiler cannot hoist these loads above the previous row's store by itself — left inside the row loop every row pays a
-// full HBM round trip in sequence
-struct EpiSide {
-    float4 r0, r1;      // residual
-    bf16x8 z;           // aux_in
-};
-
-// (the residual travels in EpiSide only with f32 output — the in-place residual stream; with bf16 output it cannot alias C and
-//  is read inline)
-template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int64_t o, int64_t orr, EpiSide& sd) {
-    if (OUT_F32 && p.residual) {
-        const float* rp = p.residual + orr;
-        sd.r0 = *(const float4*)rp; sd.r1 = *(const float4*)(rp + 4);
-    }
-    if (ACT == 3 || ACT == 4) sd.z = *(const bf16x8*)(p.aux_in + o);
-}
-
-// MODE 0: every optional operand is a run-time test (wave-uniform branches: four per 8-column unit, 80 per 320 x 256 tile and wave —
-// about 40 % of the issue slots of a plain bf16 epilogue, which is issue-bound).  MODE 1 / 2: the launch has no positional table, no
-// residual and no saved pre-activation (ACT 5 always saves its derivative), without / with bias-gradient column sums — the
-// combinations the step's bf16 GEMMs use; the tests are compiled out.
-template <int ACT, bool OUT_F32, int MODE = 0>
-__device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, int64_t o, int64_t orr,
-                                              const float (&bias)[8], float (&csum)[8], const EpiSide& sd) {
-    constexpr bool LEAN = MODE != 0;            // MODE 3: f32 output with the (in-place) residual, nothing else optional
-    // o = row * ldc + col, orr = row * ldr + col (formed incrementally by the caller)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
-    if (!LEAN && p.row_group > 0) {      // (patch-embedding GEMM only: the position-embedding rows, L2-resident)
-        const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
-        const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
-        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-    }
-    if (!LEAN && ACT != 5 && p.aux_out) {
-        bf16x8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
-        *(bf16x8*)(p.aux_out + o) = z;
-    }
-    if (ACT == 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(v[e]);
-    }
-    if (ACT == 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-    }
-    if (ACT == 3) {
-        const bf16x8 z = sd.z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
-    }
-    if (ACT == 4) {
-        const bf16x8 z = sd.z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= bf2f(z[e]);
-    }
-    if (ACT == 5) {
-        bf16x8 dz;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float g, dg;
-            gelu_erf_both_f(v[e], g, dg);
-            v[e] = g; dz[e] = f2bf(dg);
-        }
-        if (LEAN || p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
-    }
-    if (MODE == 3 || (!LEAN && p.residual)) {
-        float4 r0, r1;
-        if (OUT_F32) { r0 = sd.r0; r1 = sd.r1; }
-        else {
-            const float* rp = p.residual + orr;
-            r0 = *(const float4*)rp; r1 = *(const float4*)(rp + 4);
-        }
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-    }
-    if (OUT_F32) {
-        float* cp = (float*)p.C + o;
-        *(float4*)cp = float4{v[0], v[1], v[2], v[3]};
-        *(float4*)(cp + 4) = float4{v[4], v[5], v[6], v[7]};
-    } else {
-        bf16x8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
-        *(bf16x8*)((bf16_t*)p.C + o) = ov;
-    }
-    if (!OUT_F32 && (MODE == 2 || (MODE == 0 && p.colsum))) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) csum[e] += v[e];
-    }
-}
-
-#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // MI = 16-row MFMA tiles per wave along M: 8 -> the 256 x 256 tile, 10 -> a 320 x 256 tile.  The taller tile exists for wave
 // quantisation: a [25600, 768] output is 300 tiles of 256^2 (two rounds on 256 CUs, the second 17 % full) but 240 tiles of
@@ -1160,6 +1041,10 @@ inline GemmNT tail_rows(GemmNT p, int rows, bool out_f32) {
 
 template <int ACT>
 int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
+    {   // two co-resident 4-wave workgroups per CU (gemm_duo.hip) where the selection asks for them
+        const int rc = launch_nt_duo<ACT>(p, out_f32, st);
+        if (rc != 1) return rc;
+    }
     if (use_256(p) && !(out_f32 && p.colsum)) {      // (the 256- / 320-row kernels keep column sums only with bf16 output)
         int tm = (p.M + 255) / 256;
         const int tn = (p.N + 255) / 256;
@@ -1279,6 +1164,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
+    p.duo_prio = 0;
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
                   2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream, (int)M, (int)N, (int)K,

@@ -1,0 +1,377 @@
+// gemm_nt "duo": C[M,N] = epi(alpha * A[M,K] · B[N,K]^T) with TWO independent 4-wave workgroups per CU (gfx950).
+//
+// Why.  The 256- / 320-row kernels of gemm.hip are one 8-wave workgroup per CU (128-144 KiB LDS): while a tile is in its prologue
+// (first operands in flight) or its epilogue (stores, residual / aux reads; HBM- or issue-bound) the CU's matrix pipe idles, and
+// with K = 512 / 768 that is 30-55 % of a tile's life (tools/diag/gemm_phases.py).  Here a workgroup is 4 waves (one per SIMD)
+// with a (16 MI) x 256 tile and <= 80 KiB of LDS, so two of them share a CU, each with its own barrier and its own position in
+// its tile: one workgroup's epilogue / prologue runs under the other's main loop.  The workgroups are persistent (a static list of
+// tiles each), and the pair on a CU is kept out of lock-step by priority: main-loop MFMA clusters of the workgroup that got the
+// even wave slot run at s_setprio 2, the other's at 1, epilogues at 0 — the favoured workgroup finishes its main loop first and
+// its epilogue then overlaps the rest of the other's.
+//
+// Structure of one workgroup (wave w = column strip w of 64 columns, all 16 MI rows):
+//   * K-step 32 ("stage" = B 256 x 32 + A 16 MI x 32 bf16 = 16 + MI KiB, the [16 x 32] sub-tile image of gemm.hip with the
+//     st_16x32 swizzle), ring of 3 stages (<= 78 KiB); LDS-DMA (global_load_lds 16 B) of stage s + 2 is issued right after the
+//     barrier of stage s, so a stage has two stage-times to land; counted vmcnt, raw s_barrier, ONE barrier per stage.
+//     Every wave stages exactly the B sub-tiles it reads itself; the A sub-tiles are dealt round-robin over the waves.
+//   * software pipeline across the barrier: the stage's row tiles are split in a lower and an upper half; the upper half's MFMAs
+//     of stage s - 1 are issued AFTER the barrier of stage s, behind the LDS reads of stage s, so a wave alone on its SIMD (its
+//     neighbour in an epilogue) still has matrix work in flight while its fragments load.
+//   * MFMA operands swapped (C^T = B A^T) and B rows permuted on the global side of the LDS-DMA, as in gemm_nt256_kernel: a lane
+//     owns 8 consecutive output columns, the epilogue (gemm_common.h: epilogue_vec8) stores straight from registers.
+// Tile raster: the XCD-chunked, column-grouped order of gemm_nt256_kernel over (16 MI) x 256 tiles; workgroup i of an XCD takes
+// tiles i, i + W, i + 2 W, ... of that XCD's chunk (W workgroups per XCD).
+#include "gemm_common.h"
+
+using namespace dgemm;
+
+namespace {
+
+constexpr int DUO_B = 16 * SUB;                 // B part of a stage: 256 rows x 32 k
+
+template <int MI> struct Duo {
+    static constexpr int RH = MI / 2;
+    static constexpr int STAGE = DUO_B + MI * SUB;
+    static constexpr int LDS = 3 * STAGE;
+    static constexpr int ROWS = 16 * MI;
+    static constexpr int APMAX = (MI + 3) / 4;    // A pieces of the busiest wave
+};
+
+// per-lane byte offsets of this wave's LDS-DMA pieces inside the tile's operand panels (the k offset is wave-uniform and added to
+// the base pointers): B sub-tile j of strip `wave` holds, in LDS row rho, the operand row
+//   wave * 64 + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3)          (stage_half_perm of gemm.hip)
+template <int MI>
+__device__ __forceinline__ void duo_offsets(const GemmNT& p, int m0, int n0, int wave, int lane, unsigned (&boff)[4], unsigned (&aoff)[Duo<MI>::APMAX]) {
+    const int X = swz(lane * 16);
+    const int r = X >> 6, c = (X >> 4) & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int row = wave * 64 + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+        row = n0 + row < p.N ? row : p.N - 1 - n0;
+        boff[j] = (unsigned)row * (unsigned)(p.ldb * 2) + c * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < Duo<MI>::APMAX; ++q) {
+        const int piece = q * 4 + wave;           // row tile; pieces >= MI are not issued
+        int row = (piece < MI ? piece : 0) * 16 + r;
+        row = m0 + row < p.M ? row : p.M - 1 - m0;
+        aoff[q] = (unsigned)row * (unsigned)(p.lda * 2) + c * 16;
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void duo_issue(const char* __restrict__ Ak, const char* __restrict__ Bk, const unsigned (&boff)[4],
+                                          const unsigned (&aoff)[Duo<MI>::APMAX], char* stage, int wave) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(Bk + boff[j]), (lds_void*)(stage + (wave * 4 + j) * SUB), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < Duo<MI>::APMAX; ++q) {
+        const int piece = q * 4 + wave;
+        if (piece < MI)     // (wave-uniform)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Ak + aoff[q]), (lds_void*)(stage + DUO_B + piece * SUB), 16, 0, 0);
+    }
+}
+
+// vmcnt(n) with a run-time, wave-uniform n in {4 .. 7}: the number of LDS-DMA instructions this wave issues per stage
+#define DUO_WAIT_STAGE(g)                          \
+    do {                                           \
+        if ((g) == 7) WAIT_VMCNT(7);               \
+        else if ((g) == 6) WAIT_VMCNT(6);          \
+        else if ((g) == 5) WAIT_VMCNT(5);          \
+        else WAIT_VMCNT(4);                        \
+    } while (0)
+
+template <int ACT, bool OUT_F32, int MI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Duo<MI>;
+    constexpr int RH = G::RH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave;
+
+    // ---- which tile: the XCD-chunked, column-grouped raster of gemm_nt256_kernel (one tile per workgroup: the hardware dispatcher
+    // hands the next tile to whichever CU slot frees up first) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    int tm, tn;
+    if (p.group_n >= p.tiles_n) { tm = t / p.tiles_n; tn = t % p.tiles_n; }
+    else {
+        const int per = p.tiles_m * p.group_n;
+        const int gi = t / per, rem = t - gi * per;
+        const int left = p.tiles_n - gi * p.group_n;
+        const int gwid = left < p.group_n ? left : p.group_n;
+        tm = rem / gwid; tn = gi * p.group_n + rem % gwid;
+    }
+    const int m0 = tm * G::ROWS, n0 = tn * 256;
+
+    // ---- priority of this workgroup against the one it shares the CU with (speed only) ----
+    // duo_prio: 0 none; 1 parity of the hardware wave slot (two waves on one SIMD never share a slot; the first workgroup on an
+    // empty CU gets slot 0); 2 parity of the workgroup's index inside its XCD; 3 its upper half
+    int hi = 0;
+    {
+        const int mode = p.duo_prio;
+        if (mode == 1) hi = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) == 0;     // HW_REG_HW_ID[3:0] = WAVE_ID
+        else if (mode == 2) hi = ((blockIdx.x >> 3) & 1) == 0;
+        hi = __builtin_amdgcn_readfirstlane(hi);
+        if (mode == 1) {                          // one opinion per workgroup: wave 0's
+            int* flag = (int*)smem;
+            if (tid == 0) *flag = hi;
+            __syncthreads();
+            hi = __builtin_amdgcn_readfirstlane(*flag);
+            __syncthreads();
+        }
+    }
+
+    const int nst = p.K >> 5;                                      // stages per tile (even: K % 64 == 0)
+    const int gw = 4 + (MI - wave + 3) / 4;                        // LDS-DMA instructions of this wave per stage
+    const int fragoff = swz((lane & 15) * 64 + (lane >> 4) * 16);
+    const char* bfrag = smem + (wc * 4) * SUB + fragoff;           // + stage base: this wave's 4 column tiles
+    const char* afrag = smem + DUO_B + fragoff;                    // + stage base: row tile i at i * SUB
+
+    {
+        unsigned long long* stp = p.stamps ? p.stamps + 8 * (int64_t)blockIdx.x : nullptr;     // (8 slots per workgroup here)
+        auto stamp = [&](int k) {
+            if (stp && tid == 0) {
+                if (k == 3) WAIT_VMCNT(0);
+                stp[k] = __builtin_readcyclecounter();
+                if (k == 0) {
+                    stp[4] = __builtin_amdgcn_s_memrealtime();
+                    // where it ran: HW_REG_HW_ID (wave slot, SIMD, CU, SE ...), HW_REG_XCC_ID, and the priority it took
+                    stp[6] = (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) | ((unsigned long long)hi << 32);
+                    stp[7] = (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20);
+                }
+                if (k == 3) stp[5] = __builtin_amdgcn_s_memrealtime();
+            }
+        };
+        stamp(0);
+
+        unsigned boff[4], aoff[G::APMAX];
+        duo_offsets<MI>(p, m0, n0, wave, lane, boff, aoff);
+        const char* Ab = (const char*)(p.A + (int64_t)m0 * p.lda);
+        const char* Bb = (const char*)(p.B + (int64_t)n0 * p.ldb);
+
+        f32x4 acc[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        duo_issue<MI>(Ab, Bb, boff, aoff, smem, wave);
+        duo_issue<MI>(Ab + 64, Bb + 64, boff, aoff, smem + G::STAGE, wave);
+
+        constexpr bool BDB = MI <= 8;                 // two B fragment sets (registers permitting)
+        bf16x8 bA[4], bB[BDB ? 4 : 1], aL[RH], aH[RH];
+        // one stage: wait + barrier, request stage s + 2, read B(s) and the lower row tiles, run the UPPER half of stage s - 1 (registers
+        // only) under those reads, read the upper row tiles, run the lower half of stage s
+        auto stage_body = [&](int s, bf16x8 (&bprev)[4], bf16x8 (&bcur)[4], bool first) {
+            if (s + 1 < nst) DUO_WAIT_STAGE(gw); else WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            const int slot = s % 3;
+            if (s + 2 < nst) {
+                const int nslot = slot == 0 ? 2 : slot - 1;          // (s + 2) % 3
+                duo_issue<MI>(Ab + (s + 2) * 64, Bb + (s + 2) * 64, boff, aoff, smem + nslot * G::STAGE, wave);
+            }
+            const char* bp = bfrag + slot * G::STAGE;
+            const char* ap = afrag + slot * G::STAGE;
+            if (BDB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bcur[j] = *(const bf16x8*)(bp + j * SUB);
+            }
+#pragma unroll
+            for (int i = 0; i < RH; ++i) aL[i] = *(const bf16x8*)(ap + i * SUB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!first) {
+#pragma unroll
+                for (int i = 0; i < RH; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bprev[j], aH[i], acc[RH + i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!BDB) {     // one B fragment set (160 accumulators leave no room for two): refilled behind the MFMAs that read it
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bcur[j] = *(const bf16x8*)(bp + j * SUB);
+            }
+            WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RH; ++i) aH[i] = *(const bf16x8*)(ap + (RH + i) * SUB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RH; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], aL[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            WAIT_LGKM0();                                              // own reads of this stage retired before the next barrier (WAR)
+        };
+
+        if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+        if constexpr (BDB) {
+            stage_body(0, bB, bA, true);
+            stamp(1);
+            stage_body(1, bA, bB, false);
+            for (int s = 2; s < nst; s += 2) {
+                stage_body(s, bB, bA, false);
+                stage_body(s + 1, bA, bB, false);
+            }
+        } else {
+            stage_body(0, bA, bA, true);
+            stamp(1);
+            for (int s = 1; s < nst; ++s) stage_body(s, bA, bA, false);
+        }
+        {
+            bf16x8 (&blast)[4] = *(bf16x8 (*)[4])(BDB ? (void*)bB : (void*)bA);
+#pragma unroll
+            for (int i = 0; i < RH; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blast[j], aH[i], acc[RH + i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // (as in gemm_nt256_kernel: idle slots between the last MFMAs and the VALU that takes over their operand registers)
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+        stamp(2);
+
+        // ---- epilogue, straight from registers: lane (g, rl) owns row rl of every row tile and, per column pair jp, 8 consecutive
+        // columns (gemm_nt256_kernel's unit / batch scheme) ----
+        const int g = lane >> 4, rl = lane & 15;
+        const int colb = n0 + wc * 64 + g * 8;
+        float bias[2][8], csum[2][8];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bias[jp][e] = 0.f; csum[jp][e] = 0.f; }
+            const int col = colb + jp * 32;
+            if (p.bias && col < p.N) {
+                const float4 q0 = *(const float4*)(p.bias + col), q1 = *(const float4*)(p.bias + col + 4);
+                bias[jp][0] = q0.x; bias[jp][1] = q0.y; bias[jp][2] = q0.z; bias[jp][3] = q0.w;
+                bias[jp][4] = q1.x; bias[jp][5] = q1.y; bias[jp][6] = q1.z; bias[jp][7] = q1.w;
+            }
+        }
+        constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
+        constexpr int NU = 2 * MI;
+        constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : (MI == 6 ? 6 : 5))) : (MI == 10 ? 10 : NU));
+        static_assert(NU % BU == 0, "batch size must divide the unit count");
+        EpiSide side[SIDE ? BU : 1];
+        const int row0 = m0 + rl;
+        const int64_t o0 = (int64_t)row0 * p.ldc + colb, r0off = (int64_t)row0 * p.ldr + colb;
+        const int64_t ostep = 16 * p.ldc, rstep = 16 * p.ldr;
+        const bool full = m0 + G::ROWS <= p.M && n0 + 256 <= p.N;
+        auto run_units = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+            for (int ub = 0; ub < NU; ub += BU) {
+                if (SIDE) {
+#pragma unroll
+                    for (int u = ub; u < ub + BU; ++u) {
+                        const int i = u >> 1, jp = u & 1;
+                        if (full || (row0 + i * 16 < p.M && colb + jp * 32 < p.N))
+                            epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
+                    }
+                }
+#pragma unroll
+                for (int u = ub; u < ub + BU; ++u) {
+                    const int i = u >> 1, jp = u & 1;
+                    const int row = row0 + i * 16, col = colb + jp * 32;
+                    if (full || (row < p.M && col < p.N)) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                        epilogue_vec8<ACT, OUT_F32, MODE>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                                                          side[SIDE ? u - ub : 0]);
+                    }
+                }
+            }
+        };
+        const bool lean = p.row_group == 0 && (ACT == 5 ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT_F32 ? p.residual != nullptr : p.residual == nullptr);
+        if constexpr (OUT_F32) {
+            if (lean) run_units(std::integral_constant<int, 3>{});
+            else run_units(std::integral_constant<int, 0>{});
+        } else if constexpr (ACT == 3 || ACT == 4) {
+            if (lean && p.colsum) run_units(std::integral_constant<int, 2>{});
+            else run_units(std::integral_constant<int, 0>{});
+        } else {
+            if (lean && !p.colsum) run_units(std::integral_constant<int, 1>{});
+            else if (lean) run_units(std::integral_constant<int, 2>{});
+            else run_units(std::integral_constant<int, 0>{});
+        }
+        if (!OUT_F32 && p.colsum) {
+            // a wave holds the sums of its own 64 columns over all the tile's rows: 16-lane shuffle, then one 256-byte atomic
+            // wave-instruction per wave through LDS (the ring is idle: every wave passed the last stage's reads; the barrier at the
+            // top of the next tile keeps the next LDS-DMA away from these bytes)
+            float* cs = (float*)smem;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xs = csum[jp][e];
+                    xs += __shfl_xor(xs, 1); xs += __shfl_xor(xs, 2); xs += __shfl_xor(xs, 4); xs += __shfl_xor(xs, 8);
+                    if (rl == 0) cs[wc * 64 + jp * 32 + g * 8 + e] = xs;
+                }
+            WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            if (n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, cs[tid]);
+        }
+        stamp(3);
+    }
+}
+
+int duo_mode() { static const int m = [] { const char* e = getenv("DCLIP_GEMM_DUO"); return e ? atoi(e) : 0; }(); return m; }
+
+}  // namespace
+
+namespace dgemm {
+
+template <int ACT>
+int launch_nt_duo(GemmNT p, bool out_f32, hipStream_t st) {
+    const int mode = duo_mode();
+    if (mode == 0 || p.M < 1024 || p.N < 256 || (out_f32 && p.colsum)) return 1;
+    static const int force_mi = [] { const char* e = getenv("DCLIP_DUO_MI"); return e ? atoi(e) : 0; }();
+    static const int prio = [] { const char* e = getenv("DCLIP_DUO_PRIO"); return e ? atoi(e) : 1; }();
+    const int tn = (p.N + 255) / 256;
+    // tile height: 160 rows unless 128 rows leave fewer idle slots in the last round of 512 workgroup slots (2 per CU)
+    int mi = 10;
+    {
+        auto rounds = [&](int rows) { const int t = ((p.M + rows - 1) / rows) * tn; return (double)((t + 511) / 512) * rows; };
+        if (rounds(128) < rounds(160) * 0.98) mi = 8;
+        if (force_mi == 8 || force_mi == 10) mi = force_mi;
+    }
+    const int rows = 16 * mi;
+    p.tiles_m = (p.M + rows - 1) / rows; p.tiles_n = tn;
+    p.duo_prio = prio;
+    const int T = p.tiles_m * p.tiles_n;
+    {   // raster group width: the byte model of launch_nt (gemm.hip) with 64 concurrent tiles per XCD
+        static const int force_g = [] { const char* e = getenv("DCLIP_GEMM_GROUPN"); return e ? atoi(e) : 0; }();
+        const double panel = 512.0 * (double)p.K, a_bytes = 2.0 * (double)p.M * (double)p.K;
+        double best = 0.0; int best_g = tn;
+        for (int g = 1; g <= tn; ++g) {
+            const int ngroups = (tn + g - 1) / g;
+            const double b_term = (g * panel <= 2.5e6) ? 8.0 * g * panel * (ngroups > 8 ? ngroups / 8.0 : 1.0)
+                                                       : (double)T / 64.0 * g * panel;
+            const double cost = a_bytes * ngroups + b_term;
+            if (g == 1 || cost < best * 0.999) { best = cost; best_g = g; }
+        }
+        p.group_n = force_g > 0 ? force_g : best_g;
+    }
+    const int grid = T;
+    if (mi == 10) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_duo_kernel<ACT, true, 10>), dim3(grid), dim3(256), Duo<10>::LDS, st, p);
+        else hipLaunchKernelGGL((gemm_nt_duo_kernel<ACT, false, 10>), dim3(grid), dim3(256), Duo<10>::LDS, st, p);
+    } else {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_duo_kernel<ACT, true, 8>), dim3(grid), dim3(256), Duo<8>::LDS, st, p);
+        else hipLaunchKernelGGL((gemm_nt_duo_kernel<ACT, false, 8>), dim3(grid), dim3(256), Duo<8>::LDS, st, p);
+    }
+    return dclip_check_launch("dclip_gemm_nt");
+}
+
+template int launch_nt_duo<0>(GemmNT, bool, hipStream_t);
+template int launch_nt_duo<1>(GemmNT, bool, hipStream_t);
+template int launch_nt_duo<2>(GemmNT, bool, hipStream_t);
+template int launch_nt_duo<3>(GemmNT, bool, hipStream_t);
+template int launch_nt_duo<4>(GemmNT, bool, hipStream_t);
+template int launch_nt_duo<5>(GemmNT, bool, hipStream_t);
+
+}  // namespace dgemm

@@ -120,6 +120,7 @@ class GradSync:
         # embedding bucket (collectives of one communicator execute in issue order)
         self._streams = {}
         self._groups = {}
+        self._nkeys = 0                          # towers are keyed by the order they were attached in (the same on every rank)
         self._stream = None                      # (flat all-reduce fallback)
         self._pending = []
         # token-embedding table of the (uncompressed) text student: exchange only the rows the global batch touched
@@ -136,24 +137,44 @@ class GradSync:
         """bind the student towers: in sharded mode, plan the buckets / shards of every materialised tower once"""
         for tw in towers:
             tw.sync = self
+            if getattr(tw, '_dp_key', None) is None or getattr(tw, '_dp_owner', None) is not self:
+                # (not id(tw): an id can be reused by another object once a tower is collected)
+                tw._dp_key, tw._dp_owner = self._nkeys, self
+                self._nkeys += 1
             if self.enabled and self.sharded and tw.dp is None and tw.flat is not None:
                 self.plan(tw, tw.trainable_ranges())
-            if self.enabled and self.sharded and id(tw) not in self._groups:
+            if self.enabled and self.sharded and tw._dp_key not in self._groups:
                 # collective: every rank attaches its towers in the same order
-                self._groups[id(tw)] = dist.new_group() if os.environ.get('DCLIP_DP_TOWER_GROUPS', '1') != '0' else None
+                self._groups[tw._dp_key] = dist.new_group() if os.environ.get('DCLIP_DP_TOWER_GROUPS', '0') != '0' else None
         return self
 
+    def _key(self, tw):
+        k = getattr(tw, '_dp_key', None)
+        if k is None or getattr(tw, '_dp_owner', None) is not self:
+            self.attach([tw])
+            k = tw._dp_key
+        return k
+
     def group_for(self, tw):
-        return self._groups.get(id(tw))
+        return self._groups.get(self._key(tw))
+
+    def close(self):
+        """destroy the per-tower communicators (collective: every rank, same order) and drop the streams"""
+        for k in sorted(self._groups):
+            g = self._groups[k]
+            if g is not None and _dist_on():
+                dist.destroy_process_group(g)
+        self._groups, self._streams = {}, {}
 
     # ---- stream plumbing (no-ops for the gloo / CPU rehearsal of the same call pattern) ---------------------------
     def stream_for(self, t, tw=None):
         if not t.is_cuda:
             return None
         if tw is not None:
-            s = self._streams.get(id(tw))
+            k = self._key(tw)
+            s = self._streams.get(k)
             if s is None:
-                s = self._streams[id(tw)] = torch.cuda.Stream(device=t.device)
+                s = self._streams[k] = torch.cuda.Stream(device=t.device)
             return s
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=t.device)
@@ -206,10 +227,12 @@ class GradSync:
             s.wait_event(after)
         with GradSync._On(s):
             sp = getattr(tw, '_sparse', None)
-            if sp is not None and sp['bucket'] == i:
+            if sp is not None and sp['bucket'] == i and not sp.get('dense'):
                 self._release_sparse(tw, b, sp)
                 tw._sparse = None
             else:
+                if sp is not None and sp['bucket'] == i:
+                    tw._sparse = None                   # (a step marked dense by note_token_ids: the whole bucket travels and is cleared)
                 reduce_scatter_avg(tw.gshard[off:off + (o1 - o0)], g[b0:b1], group=self.group_for(tw))
                 g[b0:b1].zero_()                        # the backward accumulates (+=): leave the bucket clean for the next step
 
@@ -228,30 +251,41 @@ class GradSync:
         bk = tw.dp.buckets[bucket]
         if bk is None:
             return
+        if getattr(tw, '_sparse', None) is not None:
+            # a second grad-enabled forward before the bucket was released (two text forwards per step, or a forward whose
+            # backward never ran): the union of THIS call would miss the rows of the earlier one, which would then neither travel
+            # nor be cleared.  Every rank sees the same call sequence, so every rank takes the dense bucket for this step.
+            tw._sparse = dict(bucket=bucket, dense=True)
+            return
         b0, b1 = bk[0], bk[1]
-        per = (b1 - b0) // self.world
-        # table rows [r_lo, r_hi) that intersect rank k's shard [b0 + k per, b0 + (k + 1) per) — a shard boundary may cut a row, which
-        # then belongs to both neighbours' segments
-        t1 = t0 + V * D
-        seg = []
-        for k in range(self.world):
-            lo, hi = max(b0 + k * per, t0), min(b0 + (k + 1) * per, t1)
-            seg.append((0, 0) if lo >= hi else ((lo - t0) // D, (hi - t0 + D - 1) // D))
-        loc = ids.reshape(-1).to(torch.int32)
-        s = self.stream_for(loc, tw)
+        n = ids.numel()
+        cap = getattr(tw, '_sparse_cap', None)
+        if cap is None:
+            # ids per rank and forward: fixed by the FIRST forward, which also checks (one host synchronisation, once) that every rank
+            # holds the same count.  Later, smaller batches (a ragged last batch) are padded with the "no row" id V; a larger one
+            # cannot be announced to the other ranks without a collective they do not expect.
+            check_equal_batch(n, ids.device)
+            cap = tw._sparse_cap = n
+        if n > cap:
+            raise RuntimeError(f'GradSync: {n} token ids in this forward, but the row-sparse embedding exchange was sized for {cap} by '
+                               'the first forward: keep the per-rank batch <= the first one, or set DCLIP_DP_SPARSE_EMBED=0')
+        s = self.stream_for(ids, tw)
         if s is not None:
             s.wait_stream(torch.cuda.current_stream())
         with GradSync._On(s):
-            n = loc.numel()
-            allids = torch.empty(self.world * n, dtype=torch.int32, device=loc.device)
-            all_gather_flat(allids, loc.contiguous(), group=self.group_for(tw))
+            # (everything the exchange stream reads is allocated ON it: a tensor made on the compute stream and freed at the end of
+            #  this function could be handed out again by the caching allocator before this stream has read it)
+            loc = torch.full((cap,), V, dtype=torch.int32, device=ids.device)
+            loc[:n].copy_(ids.reshape(-1))
+            bounds = self._segment_bounds(tw, b0, b1, t0, V, D, ids.device)
+            allids = torch.empty(self.world * cap, dtype=torch.int32, device=loc.device)
+            all_gather_flat(allids, loc, group=self.group_for(tw))
             srt = torch.sort(allids.long()).values
             first = torch.ones_like(srt, dtype=torch.bool)
             first[1:] = srt[1:] != srt[:-1]
             pos = torch.cumsum(first.to(torch.int64), 0) - 1
-            uniq = torch.full((min(V, self.world * n),), V, dtype=torch.int64, device=loc.device)     # V = "no row" (sorts last)
+            uniq = torch.full((min(V, self.world * cap) + 1,), V, dtype=torch.int64, device=loc.device)   # V = "no row" (sorts last)
             uniq.scatter_(0, pos, srt)                   # duplicates write the same value to the same slot
-            bounds = torch.tensor([x for lo_hi in seg for x in lo_hi], dtype=torch.int64, device=loc.device)
             cuts = torch.searchsorted(uniq, bounds)      # [2 W]: first union index >= r_lo / >= r_hi of every segment
             if loc.is_cuda:
                 host = torch.empty(2 * self.world, dtype=torch.int64, pin_memory=True)
@@ -261,6 +295,25 @@ class GradSync:
             else:
                 host, ev = cuts.clone(), None
         tw._sparse = dict(bucket=bucket, t0=t0, V=V, D=D, uniq=uniq, cuts=host, cuts_dev=cuts, event=ev)
+
+    def _segment_bounds(self, tw, b0, b1, t0, V, D, device):
+        """[2 W] table rows [r_lo, r_hi) that intersect rank k's shard [b0 + k per, b0 + (k + 1) per) of the embedding bucket — a shard
+        boundary may cut a row, which then belongs to both neighbours' segments.  Built once per tower and plan and kept on the
+        device: a host list -> device tensor per step would be a blocking pageable copy in stream order, i.e. the host would wait in
+        every forward for everything enqueued so far."""
+        key = (b0, b1, t0, V, D, self.world, str(device))
+        cached = getattr(tw, '_sparse_bounds', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        per = (b1 - b0) // self.world
+        t1 = t0 + V * D
+        seg = []
+        for k in range(self.world):
+            lo, hi = max(b0 + k * per, t0), min(b0 + (k + 1) * per, t1)
+            seg += [0, 0] if lo >= hi else [(lo - t0) // D, (hi - t0 + D - 1) // D]
+        bounds = torch.tensor(seg, dtype=torch.int64, device=device)
+        tw._sparse_bounds = (key, bounds)
+        return bounds
 
     def _release_sparse(self, tw, b, sp):
         """(on the tower's exchange stream) a reduce-scatter over the TOUCHED table rows only: every rank contributes, per destination
@@ -324,7 +377,7 @@ class GradSync:
         for i in range(tw.dp_released, len(tw.dp.buckets)):
             self.bucket_ready(tw, i, after=getattr(tw, 'bwd_done', None))
         tw.dp_released = 0
-        s = self._streams.get(id(tw))
+        s = self._streams.get(self._key(tw))
         if tw.flat_grad.is_cuda and s is not None:
             done = torch.cuda.Event()
             done.record(s)

@@ -352,6 +352,83 @@ def test_row_sparse_embedding_exchange_equals_dense_reduce_scatter_world2():
                 assert float(emb[a - lo:b - lo].abs().max()) == 0.0
 
 
+def _sparse_edge_worker(rank, world, rdzv, q):
+    """the sparse exchange's assumptions, broken on purpose: two grad-enabled forwards before one backward; a ragged (smaller) batch on
+    one rank; a batch larger than the first one"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
+    from distillclip_amd.parallel import GradSync
+    out = {}
+
+    def grads(tw, id_sets, gen):
+        g = torch.zeros(_S_TOTAL)
+        for ids in id_sets:
+            rows = torch.unique(ids.reshape(-1))
+            g[:_SV * _SD].view(_SV, _SD)[rows] += torch.randn(len(rows), _SD, generator=gen)
+        g[_SV * _SD:] = torch.randn(_S_TOTAL - _SV * _SD, generator=gen)
+        tw.flat_grad.copy_(g)
+
+    def release(sync, tw):
+        for i in range(len(_S_BUCKETS)):
+            sync.bucket_ready(tw, i)
+        sync.finish(tw)
+        assert float(tw.flat_grad.abs().max()) == 0.0
+        tw.dp_unstepped.clear()                                          # (what optimizer.step() does)
+        return tw.gshard.clone()
+
+    for mode in ('sparse', 'dense'):
+        tw = _FakeTextTower(_S_TOTAL, _S_BUCKETS, [[0, _S_TOTAL]], seed=5)
+        sync = GradSync()
+        sync.sparse_embedding = mode == 'sparse'
+        sync.attach([tw])
+        gen = torch.Generator().manual_seed(70 + rank)
+        # step 1: TWO forwards (different ids) before one backward: the gradient holds the rows of both
+        ids_a = torch.randint(0, _SV, (3, 4), generator=gen)
+        ids_b = torch.randint(0, _SV, (3, 4), generator=gen)
+        grads(tw, [ids_a, ids_b], gen)
+        sync.note_token_ids(tw, ids_a)
+        sync.note_token_ids(tw, ids_b)
+        if mode == 'sparse':
+            assert tw._sparse.get('dense')                              # marked dense: the union of the last call alone would be wrong
+        out[mode + '_two_forwards'] = release(sync, tw)
+        assert getattr(tw, '_sparse', None) is None
+        # step 2: a forward whose backward never runs, then a normal step: the stale entry makes that step dense, the one after sparse
+        sync.note_token_ids(tw, ids_a)
+        ids_c = torch.randint(0, _SV, (3, 4), generator=gen)
+        grads(tw, [ids_c], gen)
+        sync.note_token_ids(tw, ids_c)
+        out[mode + '_after_skipped'] = release(sync, tw)
+        # step 3: ragged batch: rank 1 holds 2 captions instead of 3 (padded with the "no row" id on the wire)
+        ids_d = torch.randint(0, _SV, (2 if rank == 1 else 3, 4), generator=gen)
+        grads(tw, [ids_d], gen)
+        sync.note_token_ids(tw, ids_d)
+        if mode == 'sparse':
+            assert tw._sparse is not None and not tw._sparse.get('dense')
+        out[mode + '_ragged'] = release(sync, tw)
+        if mode == 'sparse':
+            out['ragged_rows'] = tw.sparse_rows_last
+            out['ragged_ids'] = ids_d
+            # a batch larger than the first forward's cannot be announced to the other ranks: refused on this rank, before any collective
+            try:
+                sync.note_token_ids(tw, torch.zeros(4, 4, dtype=torch.int64))
+                big = 'no error'
+            except RuntimeError as e:
+                big = str(e)
+            assert 'sized for 12' in big, big
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sparse_exchange_survives_two_forwards_a_skipped_backward_and_a_ragged_batch_world2():
+    res = sorted(_run_ranks(_sparse_edge_worker, 2, timeout=120), key=lambda r: r[0])
+    for rank, o in res:
+        for case in ('two_forwards', 'after_skipped', 'ragged'):
+            assert torch.equal(o['sparse_' + case], o['dense_' + case]), (rank, case, (o['sparse_' + case] - o['dense_' + case]).abs().max())
+    union = torch.unique(torch.cat([o['ragged_ids'].reshape(-1) for _, o in res]))
+    assert all(o['ragged_rows'] == len(union) for _, o in res)           # the padding ids are not rows
+
+
 def test_shard_plan_rejects_indivisible_world():
     from distillclip_amd.parallel import _Shards
     with pytest.raises(ValueError, match='not divisible'):
