@@ -422,9 +422,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
-    // the last MFMAs may still be queued in front of the matrix pipe: a dozen idle slots before the epilogue's VALU can take over
-    // the fragment registers they read (the hazard of attention_mix.hip, hw::keep_alive; once per tile)
-    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+    // (round 3 padded a dozen idle slots here against the operand re-use seen in attention_mix.hip; the static check of the shipped
+    //  object — tools/asm/mfma_hazard.py, tests/test_mfma_hazard_cpu.py — shows that no VALU instruction of the epilogue writes a
+    //  fragment register within 12 slots of the MFMAs that read it, and keeps showing it: the padding is gone)
     stamp(2);
 
     // epilogue, straight from registers (see stage_half_perm): lane (g, c) owns row c of every row tile i and, per column pair
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");      // (as in gemm_nt256_kernel: operands of queued MFMAs)
+    // (no idle slots before the epilogue: see gemm_nt256_kernel)
     stamp(2);
 
     // epilogue: 4 slabs of 64 rows through LDS, then row-contiguous f32 atomics (256 lanes x 4 B = 1 KiB per row)

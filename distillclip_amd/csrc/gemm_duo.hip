@@ -231,8 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNT p) {
                     acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blast[j], aH[i], acc[RH + i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        // (as in gemm_nt256_kernel: idle slots between the last MFMAs and the VALU that takes over their operand registers)
-        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+        // (no idle slots needed between the last MFMAs and the epilogue: tools/asm/mfma_hazard.py, tests/test_mfma_hazard_cpu.py)
         stamp(2);
 
         // ---- epilogue, straight from registers: lane (g, rl) owns row rl of every row tile and, per column pair jp, 8 consecutive
