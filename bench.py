@@ -355,6 +355,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='units per GPU (default: the configuration\'s own batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-clock-probe', action='store_true')
     ap.add_argument('--dry-launch', action='store_true', help='spawn the ranks, join a gloo group on the CPU, exit (launcher test)')
     ap.add_argument('--launch-timeout', type=float, default=1800.0, help='launcher: seconds every rank has to finish')
     ap.add_argument('--launch-grace', type=float, default=120.0, help='launcher: seconds the other ranks get after the first one exited')
@@ -451,13 +452,55 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    # shader clock actually held during the timed steps: one wave on a stream of its own samples (s_memtime, s_memrealtime) every
+    # ~0.5 ms until it is told to stop (include/dclip.h: dclip_clock_probe); roofline fractions are priced at the nominal 2.4 GHz peak
+    probe = None
+    if rank == 0 and not args.no_clock_probe:
+        nsamp = 8192
+
+        def launch_probe():
+            pr = dict(samples=torch.zeros(2 * nsamp + 1, dtype=torch.int64, device=device), stop=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                      stream=torch.cuda.Stream(device=device), n=nsamp)
+            lib().dclip_clock_probe(pr['samples'].data_ptr(), nsamp, 500, pr['stop'].data_ptr(), pr['stream'].cuda_stream)
+            return pr
+        # rehearsal outside the timed region: the wave must leave within milliseconds of the host raising the flag (otherwise the closing
+        # synchronize of the timed region would wait for the probe's whole sample budget)
+        trial = launch_probe()
+        time.sleep(0.01)
+        trial['stop'][0] = 1
+        t_flag = time.perf_counter()
+        trial['stream'].synchronize()
+        probe_ok = time.perf_counter() - t_flag < 0.1
+        if not probe_ok:
+            log('clock probe: the stop flag is not seen by the device in time; probe disabled')
+    if rank == 0 and not args.no_clock_probe and probe_ok:
+        probe = dict(samples=torch.zeros(2 * nsamp + 1, dtype=torch.int64, device=device), stop=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                     stream=torch.cuda.Stream(device=device), n=nsamp)
+        lib().dclip_clock_probe(probe['samples'].data_ptr(), nsamp, 500, probe['stop'].data_ptr(), probe['stream'].cuda_stream)
     log('timed steps')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     t_issue = time.perf_counter() - t0                      # host time to enqueue the steps (the GPU runs behind it)
+    if probe is not None:
+        # the probe wave leaves when it sees the flag: raise it once this rank's work is done, so that the device-wide synchronize of
+        # the closing barrier does not wait for the probe's sample budget instead
+        opt.join()
+        torch.cuda.current_stream().synchronize()
+        probe['stop'][0] = 1
     barrier()
     dt = time.perf_counter() - t0
+    clock = None
+    if probe is not None:
+        probe['stream'].synchronize()
+        raw = probe['samples'].cpu()
+        k = int(raw[-1])
+        if k >= 3:
+            cyc, rt = raw[0:2 * k:2].double(), raw[1:2 * k:2].double()
+            mhz = (cyc[1:] - cyc[:-1]) / (rt[1:] - rt[:-1]).clamp(min=1) * 100.0
+            clock = {'median': round(float(mhz.median()), 1), 'min': round(float(mhz.min()), 1), 'max': round(float(mhz.max()), 1),
+                     'samples': k, 'nominal': 2400.0,
+                     'how': 'one probe wave sampling s_memtime / s_memrealtime every ~0.5 ms from the first to the last timed step'}
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -544,6 +587,7 @@ def main():
             'mfma_roofline_frac_whole_step': round(value / world * wl['gflop'] * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             'final_loss': round(final_loss, 6),
             'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
+            'clock_mhz_during_timed_steps': clock,
         }
         if roofline is not None:
             out['roofline'] = roofline

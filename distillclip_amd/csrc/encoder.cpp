@@ -325,6 +325,23 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
     return dclip_cast_transpose_bf16_multi(src.data(), wb.data(), wt.data(), rr.data(), cc.data(), (int64_t)src.size(), st);
 }
 
+// The backward starts from a residual-stream gradient that is non-zero in B of the M rows (the picked class / EOT rows): its f32
+// accumulator, the bf16 copy and the fc2 operand slot of the last execution start as zeros.  Those ~2 x M x D x 4 bytes of fills
+// used to open dclip_encoder_backward, i.e. sat on the critical path right after the loss; issued here, at the end of the training
+// forward, they run on the tower's stream while the other towers finish and the loss is evaluated (the buffers are not touched by
+// the forward).
+static int clear_backward_seeds(const Plan& p, const Work& w, int64_t M, void* st) {
+    const int64_t D = p.D;
+    hipStream_t hs = (hipStream_t)st;
+    bf16_t* gb_last = w.gb_f2 + (int64_t)(p.R - 1) * M * D;
+    if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(w.Gb, 0, (size_t)M * D * 2, hs) != hipSuccess ||
+        hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) {
+        dclip_set_error("dclip_encoder_forward: memset failed");
+        return DCLIP_ELAUNCH;
+    }
+    return DCLIP_OK;
+}
+
 extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
                                      const void* wcache, void* workspace, size_t ws_bytes, int training,
                                      float* last_representation, float* const* rep_out, float* emb_out, int64_t tokens_eff,
@@ -427,6 +444,7 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
     const int f = p.p_final;
     CK(dclip_layernorm_fwd(w.X[nex], D, w.pick, PF(params, f), PF(params, f + 1), w.hf, D, 0, w.meanf, w.rstdf, B, D, 1e-5f, st));
     CK(gemm(w.hf, D, W + p.w_head, D, last_representation, E, B, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
+    if (training) CK(clear_backward_seeds(p, w, M, st));
     return DCLIP_OK;
 }
 
@@ -468,10 +486,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     auto GR = [&](int i) -> float* { return (float*)grads[i]; };
     hipStream_t hs = (hipStream_t)st;
 
-    if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(w.Gb, 0, (size_t)M * D * 2, hs) != hipSuccess) {
-        dclip_set_error("dclip_encoder_backward: memset failed");
-        return DCLIP_ELAUNCH;
-    }
+    // (w.G, w.Gb and the last execution's fc2 operand slot were cleared at the end of the training forward: clear_backward_seeds)
     // ---- head + final norm -----------------------------------------------------------------------------------
     const int f = p.p_final;
     CK(dclip_cast_bf16(d_last_representation, w.dout, B * E, st));
@@ -482,7 +497,6 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     // linear that wrote into that residual stream (fc2 of the previous execution / attn.proj of this one)
     const int R = p.R;
     bf16_t* gb_last = w.gb_f2 + (int64_t)(R - 1) * M * D;            // fc2 of the last execution reads slot R - 1
-    if (hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
     CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
                            GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
     // gradient bucket 0 (final norm + head) is complete: every launch that writes it is enqueued on `st`

@@ -328,6 +328,9 @@ template <int ACT>
 int launch_nt_duo(GemmNT p, bool out_f32, hipStream_t st) {
     const int mode = duo_mode();
     if (mode == 0 || p.M < 1024 || p.N < 256 || (out_f32 && p.colsum)) return 1;
+    // mode 1: only the shapes where the isolated A / B of round 4 showed a tie or better (f32 output + in-place residual with a short
+    // contraction: the epilogue is most of the tile's life); mode 2: every eligible shape (experiments)
+    if (mode == 1 && !(out_f32 && p.residual && p.K <= 768)) return 1;
     static const int force_mi = [] { const char* e = getenv("DCLIP_DUO_MI"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("DCLIP_DUO_PRIO"); return e ? atoi(e) : 1; }();
     const int tn = (p.N + 255) / 256;

@@ -23,7 +23,9 @@ _SLOT_CROSS = {'cos_diff': 9, 'hard_label': 10, 'soft_label': 11, 'logits_mse': 
 
 
 class _FusedLossFn(torch.autograd.Function):
+    # (autocast-safe: inputs arrive as fp32 whatever Lightning's `precision: 16` autocast did to the caller, autocast is off inside)
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, s_img, s_txt, t_img, t_txt, weights, temperature, global_negatives=False):
         two = s_txt is not None
         if global_negatives and two:
@@ -68,6 +70,7 @@ class _FusedLossFn(torch.autograd.Function):
         return scal[0].clone(), scal
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g_loss, _g_scal):
         d_i, d_t = ctx.saved_tensors
         return d_i * g_loss, (d_t * g_loss) if ctx.two else None, None, None, None, None, None
@@ -77,6 +80,7 @@ class _FeatureMSEFn(torch.autograd.Function):
     """mean((s - t)^2) with the gradient 2 (s - t) / n, both by dclip_feature_mse (hidden_mse.py / embed_mse.py)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, s, t):
         s = s.contiguous().float()
         t = t.detach().contiguous().float()
@@ -87,6 +91,7 @@ class _FeatureMSEFn(torch.autograd.Function):
         return val
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g):
         (ds,) = ctx.saved_tensors
         return ds * g, None

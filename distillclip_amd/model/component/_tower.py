@@ -4,6 +4,7 @@ Owns the flat f32 parameter / gradient buffers (parameters become views of one b
 RCCL gradient exchange see a single contiguous tensor), the bf16 weight cache and the activation workspace.
 """
 import ctypes
+import os
 
 import torch
 
@@ -287,15 +288,28 @@ class HipTower:
                                               scratch.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return out
 
-    def backward(self, x, d_out, d_reps=None, d_emb=None):
+    def backward(self, x, d_out, d_reps=None, d_emb=None, grad_flat=None):
+        """grad_flat: None = accumulate into p.grad (views of the tower's flat gradient buffer: the product path); a zeroed flat
+        buffer = write this backward's gradients there and leave p.grad to autograd (_TowerFn hands the views back as the
+        gradients of its parameter inputs, so AccumulateGrad hooks — a DistributedDataParallel reducer — see them)."""
         B = x.shape[0]
         if self._saved_batch != B:
             raise RuntimeError('backward without a matching training-mode forward (activations are kept in the workspace '
                                'of the most recent forward)')
-        self.attach_grads()
-        self._grad_clean = False                  # the kernels below accumulate into the flat gradient buffer
         ps = self._params()
-        gs = [None if (p is None or not p.requires_grad) else p.grad for p in ps]
+        if grad_flat is None:
+            self.attach_grads()
+            self._grad_clean = False              # the kernels below accumulate into the flat gradient buffer
+            gs = [None if (p is None or not p.requires_grad) else p.grad for p in ps]
+        else:
+            live_off = iter(self._offsets)
+            gs = []
+            for p in ps:
+                if p is None:
+                    gs.append(None)
+                    continue
+                off = next(live_off)
+                gs.append(grad_flat[off:off + p.numel()].view(p.shape) if p.requires_grad else None)
         if d_out is None:
             d_out = torch.zeros((B, self.cfg.out_dim), dtype=torch.float32, device=x.device)
         d_out = d_out.contiguous().float()
@@ -304,7 +318,7 @@ class HipTower:
         # data-parallel run: every gradient bucket is handed to the exchange as soon as its last writer is enqueued, so the
         # reduce-scatter of block l travels under the backward GEMMs of block l - 1
         cb, failed = None, []
-        if self.dp is not None and self.sync is not None and self.sync.enabled and self.sync.armed:
+        if grad_flat is None and self.dp is not None and self.sync is not None and self.sync.enabled and self.sync.armed:
             def _ready(_user, bucket):
                 try:
                     self.sync.bucket_ready(self, bucket)
@@ -328,32 +342,62 @@ class HipTower:
         self.bwd_stream = torch.cuda.current_stream()
         self.bwd_done.record(self.bwd_stream)
         self.grads_ready = None                    # set by the gradient exchange (event after this tower's all-reduce)
+        return gs
+
+
+def autograd_params_mode(tower):
+    """Who sees the parameter gradients.  False (default): the backward accumulates straight into p.grad — views of the tower's flat
+    buffer, which the fused optimizer and the built-in exchange consume; nothing passes through autograd's AccumulateGrad nodes.
+    True: the parameters are inputs of the autograd Function and their gradients are returned to autograd, so hooks on them fire
+    — what torch.nn.parallel.DistributedDataParallel (Lightning's ddp strategy, reference l_clip.yaml:56) needs to find, bucket
+    and all-reduce them; costs one zero-fill of a gradient buffer per backward plus autograd's own accumulation pass.
+    Chosen by DCLIP_DP_MODE=off (an outer wrapper owns the exchange) or per tower through `tower.autograd_params`."""
+    forced = getattr(tower, 'autograd_params', None)
+    if forced is not None:
+        return bool(forced)
+    return os.environ.get('DCLIP_DP_MODE', '') == 'off'
 
 
 class _TowerFn(torch.autograd.Function):
-    """autograd edge of a student tower: forward / backward are one C-ABI call each."""
+    """autograd edge of a student tower: forward / backward are one C-ABI call each.  Safe under torch.autocast (Lightning
+    `precision: 16`, reference l_clip.yaml:64): floating inputs arrive as fp32, autocast is off inside, and the backward runs in
+    the forward's autocast state; a GradScaler's scale reaches the kernels through d_out and leaves through unscale_ on p.grad."""
 
     @staticmethod
-    def forward(ctx, anchor, x, tower, need_rep, need_emb):
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, anchor, x, tower, need_rep, need_emb, *params):
         out, xin, reps, emb = tower.forward(x, training=True, need_rep=need_rep, need_emb=need_emb)
         ctx.tower = tower
         ctx.x = xin
         ctx.n_rep = len(reps)
         ctx.has_emb = emb is not None
+        ctx.n_params = len(params)
         return (out,) + tuple(reps) + ((emb,) if emb is not None else ())
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, d_out, *rest):
         d_reps = list(rest[:ctx.n_rep])
         d_emb = rest[ctx.n_rep] if ctx.has_emb else None
-        ctx.tower.backward(ctx.x, d_out, d_reps, d_emb)
-        return None, None, None, None, None
+        tower = ctx.tower
+        if not ctx.n_params:
+            tower.backward(ctx.x, d_out, d_reps, d_emb)
+            return None, None, None, None, None
+        # a buffer of its own per backward: autograd may keep the returned views as p.grad (no copy), and the next backward must not
+        # write into them
+        grad_flat = torch.zeros_like(tower.flat)
+        gs = tower.backward(ctx.x, d_out, d_reps, d_emb, grad_flat=grad_flat)
+        return (None, None, None, None, None) + tuple(g for p, g in zip(tower._params(), gs) if p is not None)
 
 
 def run_tower(tower, x, anchor, need_rep=False, need_emb=False):
     """-> (last_representation, [hidden state per block execution], embedding or None)"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in tower.module.parameters()):
-        res = _TowerFn.apply(anchor, x, tower, need_rep, need_emb)
+        params = ()
+        if autograd_params_mode(tower):
+            tower.materialize(x.device)            # the parameters must already be the views of the flat buffer they will stay
+            params = tuple(p for p in tower._params() if p is not None)
+        res = _TowerFn.apply(anchor, x, tower, need_rep, need_emb, *params)
         nex = tower.cfg.layers * tower.cfg.repeats if need_rep else 0
         return res[0], list(res[1:1 + nex]), (res[1 + nex] if need_emb else None)
     out, _, reps, emb = tower.forward(x, training=False, need_rep=need_rep, need_emb=need_emb)

@@ -384,6 +384,11 @@ int dclip_trace_gemm_stamps(void* buf);
 /* same for the head-mixing softmax backward: 8 uint64 per (wave, row iteration < 4): s_memtime at row start / operands in LDS /
  * row sums done / key tiles done / dW_l done (tools/diag/attn_phases.py) */
 int dclip_trace_attn_stamps(void* buf);
+/* measurement only (bench.py `clock_mhz_during_timed_steps`): ONE wave that, on `stream`, writes up to `max_samples` pairs
+ * (s_memtime = shader cycles, s_memrealtime = 100 MHz ticks) into samples[2 * i ..], about `interval_us` apart, and leaves as soon as
+ * *stop (host-pinned or device memory, polled uncached) is non-zero or the samples are used up; samples[2 * max_samples] receives the
+ * number written.  shader clock over an interval = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back). */
+int dclip_clock_probe(uint64_t* samples, int64_t max_samples, int64_t interval_us, const int32_t* stop, void* stream);
 
 #ifdef __cplusplus
 }

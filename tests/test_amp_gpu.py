@@ -1,0 +1,106 @@
+"""`precision: 16` (reference l_clip.yaml:64, image.yaml:69, text.yaml:52) = Lightning's fp16 autocast + GradScaler around
+training_step / backward / optimizer.step.  The towers and the fused loss run their own mixed precision (bf16 operands, f32 accumulate),
+so what has to hold is that the wrapper does not change anything: same loss inside torch.autocast as outside, and
+scale -> backward -> unscale_ on the p.grad views of the flat buffers gives back the unscaled gradients (every kernel is linear in
+d_out and the scale is a power of two, so apart from the column-sum atomics the bits are the same)."""
+import numpy as np
+import pytest
+import torch
+
+from distillclip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+S_IMG = dict(img_size=32, patch_size=8, in_chans=3, out_dim=64, embed_dim=128, depth=4, num_heads=4, mlp_ratio=4.0,
+             qkv_bias=True, repeated_times=2, use_transform=True)
+S_TXT = dict(vocab_size=97, context_length=13, out_dim=64, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4.0,
+             qkv_bias=False, repeated_times=2, use_transform=True)
+SEED, B = 33, 6
+LOSS = dict(loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})
+
+
+def T(d):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def _build(norm=False):
+    from distillclip_amd.model import DualDistillModel
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    si, st = RepeatVisionTransformer(**S_IMG), RepeatTextTransformer(**S_TXT)
+    si.load_state_dict(T(synth.student_image_state(SEED, **S_IMG)))
+    st.load_state_dict(T(synth.student_text_state(SEED, **S_TXT)))
+    tsd = T(synth.teacher_image_state(SEED, 128, 2, 8, 32, 64))
+    tsd.update(T(synth.teacher_text_state(SEED, 128, 2, 13, 97, 64)))
+    return DualDistillModel(si, st, LOSS, 0, 10, 1e-2, 1e-3, '.', teacher_state_dict=tsd, norm=norm).cuda()
+
+
+def _batch():
+    return [torch.from_numpy(synth.images(SEED, B, 32)).cuda(), torch.from_numpy(synth.captions(SEED, B, 13, 97, 3, 9)).cuda()]
+
+
+def _grads(model):
+    return {n: p.grad.detach().clone() for n, p in model.student.named_parameters() if p.requires_grad}
+
+
+@pytest.mark.parametrize('norm', [False, True])
+@pytest.mark.parametrize('through_autograd', [False, True])
+def test_autocast_and_gradscaler_leave_loss_and_gradients_unchanged(through_autograd, norm):
+    batch = _batch()
+    plain = _build(norm)
+    for tw in plain.towers():
+        tw.autograd_params = through_autograd
+    loss0 = plain.training_step(batch)
+    loss0.backward()
+    g0 = _grads(plain)
+
+    amp = _build(norm)
+    for tw in amp.towers():
+        tw.autograd_params = through_autograd
+    params = [p for p in amp.parameters() if p.requires_grad]           # reference dual_distill_model.py:195
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-2)
+    scaler = torch.amp.GradScaler('cuda', init_scale=65536.0)
+    with torch.autocast('cuda', dtype=torch.float16):
+        loss1 = amp.training_step(batch)
+    assert loss1.dtype == torch.float32
+    assert abs(loss1.item() - loss0.item()) <= 1e-6 * abs(loss0.item())
+    scaler.scale(loss1).backward()
+    scaled = _grads(amp)
+    scaler.unscale_(opt)
+    g1 = _grads(amp)
+    worst = 0.0
+    for n in g0:
+        assert torch.isfinite(g1[n]).all(), n
+        d = (g1[n] - g0[n]).norm().item() / (g0[n].norm().item() + 1e-30)
+        worst = max(worst, d)
+        # the scaled gradients really were scaled (the scale went through the kernels, it was not applied afterwards)
+        assert (scaled[n].norm().item() + 1e-30) / (g0[n].norm().item() + 1e-30) == pytest.approx(65536.0, rel=1e-3) or g0[n].norm().item() == 0
+    assert worst <= 2e-6, worst
+    before = {n: p.detach().clone() for n, p in amp.student.named_parameters() if p.requires_grad}
+    scaler.step(opt)
+    scaler.update()
+    assert scaler.get_scale() == 65536.0                                 # no inf / nan was found
+    moved = sum(float((p.detach() - before[n]).abs().max()) > 0 for n, p in amp.student.named_parameters() if p.requires_grad)
+    assert moved == len(before)
+    # the next forward sees the updated masters (bf16 weight cache re-cast) and still matches a plain model given the same weights
+    with torch.autocast('cuda', dtype=torch.float16):
+        loss2 = amp.training_step(batch)
+    assert loss2.item() != loss1.item()
+
+
+def test_gradscaler_skips_the_step_on_overflow():
+    """an inf in d_out must surface as a non-finite gradient so that GradScaler.step skips the update and halves the scale"""
+    batch = _batch()
+    m = _build()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    scaler = torch.amp.GradScaler('cuda', init_scale=65536.0)
+    with torch.autocast('cuda', dtype=torch.float16):
+        loss = m.training_step(batch)
+    (scaler.scale(loss) * float('inf')).backward()
+    before = {n: p.detach().clone() for n, p in m.student.named_parameters() if p.requires_grad}
+    scaler.step(opt)
+    scaler.update()
+    assert scaler.get_scale() == 32768.0
+    for n, p in m.student.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.detach(), before[n]), n

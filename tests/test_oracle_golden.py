@@ -187,6 +187,43 @@ def test_loss_components(golden_dir, case):
         np.testing.assert_allclose(e[k].grad.numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
 
 
+def test_real_shapes_gradients_of_every_parameter_match_the_reference(golden_dir):
+    """real_b4_cos.npz (round 4; tools/golden/gen_golden.py:real_shapes_cos_slices): the reference's gradients of EVERY student parameter
+    at the shipped shapes (H = 24 / hd = 32 / N = 50 and H = 12 / hd = 64 / N = 77), B = 4, smooth objective — the head of each tensor
+    and 256 elements spread over it.  Pins the oracle's backward at real shapes; the HIP path is held to the same file on the GPU."""
+    g = dict(np.load(os.path.join(golden_dir, 'real_b4_cos.npz')))
+    seed, B = int(g['seed']), int(g['B'])
+    s_img_cfg = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                     mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    text = torch.from_numpy(synth.captions(seed, B))
+    sd_i = T(synth.student_image_state(seed, **s_img_cfg), grad=True)
+    sd_t = T(synth.student_text_state(seed, **s_txt_cfg), grad=True)
+    with torch.no_grad():
+        to = oracle.clip_forward(oracle.teacher_image_forward(T(synth.teacher_image_state(seed)), image),
+                                 oracle.teacher_text_forward(T(synth.teacher_text_state(seed)), text))
+    so = oracle.clip_forward(oracle.student_image_forward(sd_i, image, 24), oracle.student_text_forward(sd_t, text, 12))
+    loss, _ = oracle.LossOracle(['out_cos'])(so, to, 'all')
+    close(loss, g['cos.loss'], rtol=2e-5)
+    loss.backward()
+    n_checked = 0
+    for tag, sd in (('s_img', sd_i), ('s_txt', sd_t)):
+        for n, p in sd.items():
+            key = f'cos.{tag}.gnorm.{n}'
+            if key not in g:
+                continue
+            gr = p.grad.reshape(-1)
+            ref_norm = float(g[key])
+            assert abs(float(gr.norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-12, (tag, n)
+            step = max(1, gr.numel() // 256)
+            for kind, got in (('ghead', gr[:256]), ('gspread', gr[::step][:256])):
+                ref = g[f'cos.{tag}.{kind}.{n}']
+                np.testing.assert_allclose(got.numpy(), ref, rtol=5e-4, atol=5e-4 * max(np.abs(ref).max(), 1e-12), err_msg=f'{tag}.{n}.{kind}')
+            n_checked += 1
+    assert n_checked == 68 + 44
+
+
 def test_metrics_known_answers():
     """validation metrics restatement (oracle/metrics.py) on hand-computable cases: a permutation structure fixes every
     rank, and the diagonal scores follow from the logits in closed form."""

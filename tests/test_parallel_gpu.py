@@ -161,6 +161,71 @@ def test_two_ranks_global_negatives_equal_one_process_on_the_concatenated_batch(
     _close_params(sd0, {k: v.detach().cpu() for k, v in model.student.state_dict().items()}, LR * STEPS)
 
 
+def _ddp_rank(rank, world, rdzv, loss, q):
+    """the reference's strategy literally: torch DistributedDataParallel around the module, plain loss.backward(); our own exchange off"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', DCLIP_DP_MODE='off')
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
+    model = _build(loss)
+    image, text = _data()
+    img, txt = image[rank * B:(rank + 1) * B].cuda(), text[rank * B:(rank + 1) * B].cuda()
+    model.training_step([img, txt])                                # materialise the flat buffers before DDP looks at the parameters
+    for p in model.parameters():
+        p.grad = None
+    ddp = DDP(model, device_ids=[0], find_unused_parameters=False)  # l_clip.yaml:56 ddp_find_unused_parameters_false
+    out = []
+    for _ in range(2):                                              # two iterations: the reducer must have finished the first
+        for p in model.parameters():
+            p.grad = None
+        s_out, t_out = ddp([img, txt])
+        lt, _ = model.loss_control(s_out, t_out, 'all')
+        lt.backward()
+        torch.cuda.synchronize()
+        out.append({n: p.grad.detach().cpu().numpy().copy() for n, p in model.student.named_parameters() if p.requires_grad})
+    q.put((rank, out, lt.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wrapper_averages_the_gradients_when_the_builtin_exchange_is_off():
+    """DCLIP_DP_MODE=off + torch.nn.parallel.DistributedDataParallel (what Lightning's ddp strategy builds): the parameter gradients
+    travel through autograd (tower.autograd_params mode), so the reducer's hooks fire and p.grad ends up as the average over the
+    ranks — compared with one process that runs both shards and averages."""
+    import shutil
+    import tempfile
+    loss = dict(loss_name=['out_cos', 'out_l1', 'cos_diff'], loss_scale={'cos_diff': 0.1})
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    d = tempfile.mkdtemp(prefix='dclip_rdzv_')
+    ps = [ctx.Process(target=_ddp_rank, args=(r, 2, os.path.join(d, 'store'), loss, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=600) for _ in ps], key=lambda r: r[0])
+        for p in ps:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+        shutil.rmtree(d, ignore_errors=True)
+    (_, g0, _), (_, g1, _) = res
+    model = _build(loss)
+    image, text = _data()
+    for r in range(2):
+        lt = model.training_step([image[r * B:(r + 1) * B].cuda(), text[r * B:(r + 1) * B].cuda()])
+        lt.backward()                                               # accumulates (+=) into the flat buffers
+    want = {n: (p.grad.detach() * 0.5).cpu().numpy() for n, p in model.student.named_parameters() if p.requires_grad}
+    for it in range(2):
+        for n in want:
+            assert np.array_equal(g0[it][n], g1[it][n]), n          # both ranks hold the same average
+            num = np.linalg.norm(g0[it][n] - want[n])
+            assert num <= 1e-5 * np.linalg.norm(want[n]) + 1e-9, (it, n, num)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL refuses two ranks on one device')
 def test_two_ranks_over_rccl_on_two_devices():
     """The same two-rank run over the real wire (backend "nccl" = RCCL, one device per rank) wherever the box has two GPUs: identical

@@ -290,6 +290,42 @@ def real_shapes():
     print('real_b4.npz', len(out), 'arrays', 'loss', float(loss))
 
 
+def real_shapes_cos_slices():
+    """Round 4: gradient slices of EVERY student parameter at real shapes (ViT-B/32 teacher + the shipped l_clip students, B = 4, the
+    smooth out_cos objective, as in real_shapes()): the first 256 elements and 256 elements spread evenly over the tensor.  A separate
+    file, so that real_b4.npz stays byte-identical."""
+    seed, B = 2022, 4
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    text = torch.from_numpy(synth.captions(seed, B))
+    t_img = build_teacher_image(seed, 768, 12, 32, 224, 512)
+    t_txt = build_teacher_text(seed, 512, 12, 77, 49408, 512)
+    s_img_cfg = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                     mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+    s_txt_cfg = dict(depth=4, repeated_times=2, use_transform=True)
+    s_img = build_student_image(seed, **s_img_cfg)
+    s_txt = build_student_text(seed, **s_txt_cfg)
+    student = CLIPModel(True, s_img, s_txt, False)
+    teacher = CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    lc2 = quiet(LossCalculator, loss_name=['out_cos'])
+    so = student(text, image, lc2.get_control_output())
+    with torch.no_grad():
+        to = teacher(text, image, lc2.get_control_output())
+    loss2, _ = lc2(so, to, 'all')
+    loss2.backward()
+    out = {'seed': np.int64(seed), 'B': np.int64(B), 'cos.loss': np_(loss2)}
+    for tag, m in (('s_img', s_img), ('s_txt', s_txt)):
+        for n, p in m.named_parameters():
+            g = p.grad.reshape(-1)
+            out[f'cos.{tag}.gnorm.{n}'] = np_(g.norm())
+            out[f'cos.{tag}.ghead.{n}'] = np_(g[:256])
+            step = max(1, g.numel() // 256)
+            out[f'cos.{tag}.gspread.{n}'] = np_(g[::step][:256])
+    np.savez_compressed(os.path.join(OUT, 'real_b4_cos.npz'), **out)
+    print('real_b4_cos.npz', len(out), 'arrays', 'loss', float(loss2))
+
+
 def _train(student, teacher, s_img, s_txt, batches, lr, wd, warm, total, steps_per_epoch, tag, out):
     """The reference's training loop arithmetic without the Lightning shell: dual_distill_model.py:120-127 (training_step:
     student fwd, teacher fwd, LossCalculator) + what Lightning's automatic optimisation does around it (zero_grad, backward,
@@ -385,3 +421,5 @@ if __name__ == '__main__':
         loss_only()
     if 'real' in which:
         real_shapes()
+    if 'real_cos' in which:
+        real_shapes_cos_slices()
