@@ -452,55 +452,32 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
-    # shader clock actually held during the timed steps: one wave on a stream of its own samples (s_memtime, s_memrealtime) every
-    # ~0.5 ms until it is told to stop (include/dclip.h: dclip_clock_probe); roofline fractions are priced at the nominal 2.4 GHz peak
-    probe = None
+    # shader clock actually held inside the dominant kernel during the timed steps: workgroup 0 of every 256- / 320-row gemm_nt launch
+    # stamps (s_memtime, s_memrealtime) at its start and end (include/dclip.h: dclip_trace_gemm_clock; one thread per launch, no extra
+    # kernel).  Roofline fractions are priced at the nominal 2.4 GHz peak; this says what the chip held.
+    clock_buf = None
     if rank == 0 and not args.no_clock_probe:
-        nsamp = 8192
-
-        def launch_probe():
-            pr = dict(samples=torch.zeros(2 * nsamp + 1, dtype=torch.int64, device=device), stop=torch.zeros(1, dtype=torch.int32).pin_memory(),
-                      stream=torch.cuda.Stream(device=device), n=nsamp)
-            lib().dclip_clock_probe(pr['samples'].data_ptr(), nsamp, 500, pr['stop'].data_ptr(), pr['stream'].cuda_stream)
-            return pr
-        # rehearsal outside the timed region: the wave must leave within milliseconds of the host raising the flag (otherwise the closing
-        # synchronize of the timed region would wait for the probe's whole sample budget)
-        trial = launch_probe()
-        time.sleep(0.01)
-        trial['stop'][0] = 1
-        t_flag = time.perf_counter()
-        trial['stream'].synchronize()
-        probe_ok = time.perf_counter() - t_flag < 0.1
-        if not probe_ok:
-            log('clock probe: the stop flag is not seen by the device in time; probe disabled')
-    if rank == 0 and not args.no_clock_probe and probe_ok:
-        probe = dict(samples=torch.zeros(2 * nsamp + 1, dtype=torch.int64, device=device), stop=torch.zeros(1, dtype=torch.int32).pin_memory(),
-                     stream=torch.cuda.Stream(device=device), n=nsamp)
-        lib().dclip_clock_probe(probe['samples'].data_ptr(), nsamp, 500, probe['stop'].data_ptr(), probe['stream'].cuda_stream)
+        clock_cap = 16384
+        clock_buf = torch.zeros(4 * clock_cap, dtype=torch.int64, device=device)
+        lib().dclip_trace_gemm_clock(clock_buf.data_ptr(), clock_cap)
     log('timed steps')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     t_issue = time.perf_counter() - t0                      # host time to enqueue the steps (the GPU runs behind it)
-    if probe is not None:
-        # the probe wave leaves when it sees the flag: raise it once this rank's work is done, so that the device-wide synchronize of
-        # the closing barrier does not wait for the probe's sample budget instead
-        opt.join()
-        torch.cuda.current_stream().synchronize()
-        probe['stop'][0] = 1
     barrier()
     dt = time.perf_counter() - t0
     clock = None
-    if probe is not None:
-        probe['stream'].synchronize()
-        raw = probe['samples'].cpu()
-        k = int(raw[-1])
-        if k >= 3:
-            cyc, rt = raw[0:2 * k:2].double(), raw[1:2 * k:2].double()
-            mhz = (cyc[1:] - cyc[:-1]) / (rt[1:] - rt[:-1]).clamp(min=1) * 100.0
-            clock = {'median': round(float(mhz.median()), 1), 'min': round(float(mhz.min()), 1), 'max': round(float(mhz.max()), 1),
-                     'samples': k, 'nominal': 2400.0,
-                     'how': 'one probe wave sampling s_memtime / s_memrealtime every ~0.5 ms from the first to the last timed step'}
+    if clock_buf is not None:
+        n_stamped = min(int(lib().dclip_trace_gemm_clock(None, 0)), clock_cap)
+        raw = clock_buf.view(-1, 4)[:n_stamped].cpu().double()
+        ok = (raw[:, 3] > raw[:, 1]) & (raw[:, 2] > raw[:, 0])
+        if int(ok.sum()) >= 8:
+            mhz = ((raw[ok, 2] - raw[ok, 0]) / (raw[ok, 3] - raw[ok, 1]) * 100.0).sort().values
+            q = lambda f: round(float(mhz[min(len(mhz) - 1, int(f * len(mhz)))]), 1)
+            clock = {'median': q(0.5), 'p10': q(0.1), 'p90': q(0.9), 'launches': int(ok.sum()), 'nominal': 2400.0,
+                     'how': 'workgroup 0 of every 256-/320-row gemm_nt launch of the timed steps: d(s_memtime) / d(s_memrealtime) x 100 MHz '
+                            'over the workgroup\'s lifetime'}
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -509,27 +509,3 @@ extern "C" int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int6
     return dclip_check_launch("dclip_axpy_f32");
 }
 
-// ---- shader-clock probe (measurement only) --------------------------------------------------------------------------
-// one wave; bounded: at most max_samples iterations of a bounded sleep, early exit on *stop
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* samples, long long max_samples, int sleeps, const int* stop) {
-    if (threadIdx.x != 0) return;
-    long long n = 0;
-    for (; n < max_samples; ++n) {
-        samples[2 * n] = __builtin_amdgcn_s_memtime();
-        samples[2 * n + 1] = __builtin_amdgcn_s_memrealtime();
-        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { ++n; break; }
-        for (int k = 0; k < sleeps; ++k) __builtin_amdgcn_s_sleep(127);          // 127 x 64 cycles per s_sleep
-    }
-    samples[2 * max_samples] = (unsigned long long)n;
-}
-
-extern "C" int dclip_clock_probe(uint64_t* samples, int64_t max_samples, int64_t interval_us, const int32_t* stop, void* stream) {
-    DCLIP_REQUIRE(samples && stop && max_samples > 0 && max_samples <= (1 << 20) && interval_us > 0 && interval_us <= 100000,
-                  "dclip_clock_probe: bad argument");
-    // s_sleep 127 = 8 128 cycles ~ 4 us at 2 GHz
-    int sleeps = (int)(interval_us / 4);
-    if (sleeps < 1) sleeps = 1;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)samples, (long long)max_samples,
-                       sleeps, (const int*)stop);
-    return dclip_check_launch("dclip_clock_probe");
-}

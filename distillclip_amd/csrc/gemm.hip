@@ -11,6 +11,7 @@
 // ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
 
 #include "gemm_common.h"
+#include <atomic>
 
 using namespace dgemm;
 
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         }
     };
     stamp(0);
+    if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
     // LDS-DMA instructions per wave: B half 2, A row-half 2 (RH = 4) or 3 (RH = 5).  vmcnt completes in issue order, so "wait
     // until half-tile X has landed" = vmcnt(number of instructions issued after X)
 #define WAIT_VM2(n8, n10) do { if (MI == 10) WAIT_VMCNT(n10); else WAIT_VMCNT(n8); } while (0)
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         if (tid < 256 && n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, cs[tid] + cs[256 + tid]);
     }
     stamp(3);
+    if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1136,10 +1139,21 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
 }
 
 unsigned long long* g_gemm_stamps = nullptr;
+std::atomic<long long> g_tn_atomic_fallbacks{0};
+unsigned long long* g_clock_buf = nullptr;
+long long g_clock_cap = 0;
+std::atomic<long long> g_clock_count{0};
 
 }  // namespace
 
 extern "C" int dclip_trace_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return 0; }
+extern "C" int64_t dclip_trace_gemm_clock(void* buf, int64_t cap) {
+    const long long n = g_clock_count.exchange(0, std::memory_order_relaxed);
+    g_clock_buf = (unsigned long long*)buf;
+    g_clock_cap = buf ? (long long)cap : 0;
+    return (int64_t)n;
+}
+extern "C" int64_t dclip_gemm_tn_atomic_fallbacks(void) { return (int64_t)g_tn_atomic_fallbacks.load(std::memory_order_relaxed); }
 
 extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                              int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
@@ -1165,6 +1179,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
     p.duo_prio = 0;
+    p.clk = nullptr;
+    if (g_clock_buf && g_clock_cap > 0) p.clk = g_clock_buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % g_clock_cap);
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
                   2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream, (int)M, (int)N, (int)K,
@@ -1219,6 +1235,9 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
         static const int tn_partial = [] { const char* e = getenv("DCLIP_TN_PARTIAL"); return e ? atoi(e) : 1; }();
         const size_t need = (size_t)tiles * q.splits * 65536 * sizeof(float);
         const bool part = tn_partial != 0 && workspace && ws_bytes >= need && ldo % 4 == 0 && ((uintptr_t)dW % 16) == 0 && q.splits > 1;
+        // (diagnostic: the f32-atomic path is correct but not run-to-run identical; callers that rely on bit-reproducible wgrads
+        //  check that this counter stays at zero)
+        if (!part && q.splits > 1) g_tn_atomic_fallbacks.fetch_add(1, std::memory_order_relaxed);
         q.partial = part ? (float*)workspace : nullptr;
         hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 8 * HT, (hipStream_t)stream, q);
         if (part)

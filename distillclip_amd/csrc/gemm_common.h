@@ -26,6 +26,7 @@ struct GemmNT {
     int tiles_m, tiles_n;
     unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps): 6 x u64 per workgroup, else null
     int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
+    unsigned long long* clk;                        // measurement only (dclip_trace_gemm_clock): 4 x u64 of this launch, else null
     int duo_prio;                                   // gemm_duo.hip: how a workgroup picks its priority against its CU neighbour
 };
 

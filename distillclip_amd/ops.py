@@ -44,9 +44,11 @@ _TN_WS = {}
 
 
 def _tn_workspace(device):
-    ws = _TN_WS.get(device)
+    # one workspace per (device, stream): two wgrad calls enqueued on different streams must not share partial tiles
+    key = (device, _stream())
+    ws = _TN_WS.get(key)
     if ws is None:
-        ws = _TN_WS[device] = torch.empty(lib().dclip_gemm_tn_workspace_bytes(), dtype=torch.uint8, device=device)
+        ws = _TN_WS[key] = torch.empty(lib().dclip_gemm_tn_workspace_bytes(), dtype=torch.uint8, device=device)
     return ws
 
 

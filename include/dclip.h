@@ -66,6 +66,9 @@ int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
  * split's partial tile with plain stores and a second launch adds the splits to dW in a fixed order (no f32 atomics: faster,
  * and run-to-run identical); without it, or for outputs on the small-tile kernels, f32 atomics as before. */
 size_t dclip_gemm_tn_workspace_bytes(void);
+/* diagnostic (process-global counter): how many 256 x 256 wgrad launches so far had to fall back from the partial-tile path (run-to-run
+ * identical) to f32 atomics because no / too small a workspace was passed */
+int64_t dclip_gemm_tn_atomic_fallbacks(void);
 int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t ldo,
                       int64_t M, int64_t P, int64_t Q, int splits, void* workspace, size_t ws_bytes, void* stream);
 
@@ -384,11 +387,12 @@ int dclip_trace_gemm_stamps(void* buf);
 /* same for the head-mixing softmax backward: 8 uint64 per (wave, row iteration < 4): s_memtime at row start / operands in LDS /
  * row sums done / key tiles done / dW_l done (tools/diag/attn_phases.py) */
 int dclip_trace_attn_stamps(void* buf);
-/* measurement only (bench.py `clock_mhz_during_timed_steps`): ONE wave that, on `stream`, writes up to `max_samples` pairs
- * (s_memtime = shader cycles, s_memrealtime = 100 MHz ticks) into samples[2 * i ..], about `interval_us` apart, and leaves as soon as
- * *stop (host-pinned or device memory, polled uncached) is non-zero or the samples are used up; samples[2 * max_samples] receives the
- * number written.  shader clock over an interval = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back). */
-int dclip_clock_probe(uint64_t* samples, int64_t max_samples, int64_t interval_us, const int32_t* stop, void* stream);
+/* measurement only (bench.py `clock_mhz_during_timed_steps`; process-global): while `buf` is non-NULL, workgroup 0 of every 256- / 320-row
+ * dclip_gemm_nt launch writes 4 uint64 — s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and at its end — to
+ * buf[4 * (launch % cap) ..]; shader clock held during that launch = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS
+ * give-back).  One thread of one workgroup per launch: the timed steps are not perturbed (a resident probe wave on a stream of its own
+ * cost 1.7 % of the step and was dropped).  Returns the number of launches stamped since the previous call; NULL switches it off. */
+int64_t dclip_trace_gemm_clock(void* buf, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -179,10 +179,14 @@ def test_whole_training_step_at_full_batch(config):
     (opt,), _ = model.configure_optimizers()
     image, text, _ = bench.make_inputs(wl, 2022, wl['batch'])
     batch = [image.cuda(), text.cuda()] if wl['kind'] == 'dual' else (image.cuda() if wl['kind'] == 'image' else text.cuda())
+    from distillclip_amd._lib import lib
+    fallbacks = lib().dclip_gemm_tn_atomic_fallbacks()
     loss = model.training_step(batch)
     opt.zero_grad()
     model.backward_and_sync(loss)
     torch.cuda.synchronize()
+    # every large wgrad of the step found its workspace: none fell back to f32 atomics (the run-to-run determinism claim)
+    assert lib().dclip_gemm_tn_atomic_fallbacks() == fallbacks
     assert torch.isfinite(loss) and 0.05 < loss.item() < 5.0, loss.item()
     n = 0
     for name, p in model.student.named_parameters():

@@ -413,9 +413,10 @@ def test_real_shapes_b4_every_parameter_gradient_vs_reference_golden(golden_dir)
     top = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
     print('real-shape gradient parity vs the reference (fp32): worst slices', top, 'worst norms', sorted(norms.items(), key=lambda kv: -kv[1])[:4])
     assert len(errs) >= 100
-    bad = {k: v for k, v in errs.items() if v > (1.5e-1 if ('conv_' in k or 'bias' in k or 'norm' in k) else 8e-2)}
+    # measured (default path): slices <= 2.2e-2, norms <= 5e-3
+    bad = {k: v for k, v in errs.items() if v > (8e-2 if ('conv_' in k or 'bias' in k or 'norm' in k) else 5e-2)}
     assert not bad, bad
-    assert max(norms.values()) < 6e-2, sorted(norms.items(), key=lambda kv: -kv[1])[:4]
+    assert max(norms.values()) < 2e-2, sorted(norms.items(), key=lambda kv: -kv[1])[:4]
 
 
 def test_real_shapes_b4_backward_vs_rounding_matched_oracle():
@@ -460,7 +461,10 @@ def test_real_shapes_b4_backward_vs_rounding_matched_oracle():
     print('real-shape matched-oracle parity: loss', abs(loss.item() - ol.item()) / abs(ol.item()), 'embeddings', e_emb, 'worst gradients', top)
     assert abs(loss.item() - ol.item()) <= 2e-3 * abs(ol.item())
     assert max(e_emb.values()) < 5e-3, e_emb
-    bad = {n: e for n, e in errs.items() if e > 2.5e-2}
+    # measured <= 1.3e-2 on the default path.  The matched oracle rounds where THAT path stores bf16; the unfused fallback
+    # (DCLIP_ATTN_MIX=0: scores and probabilities through HBM) rounds at other points of the score stage: <= 3.1e-2 on the conv_l weights
+    bound = 2.5e-2 if os.environ.get('DCLIP_ATTN_MIX', '1') != '0' else 4e-2
+    bad = {n: e for n, e in errs.items() if e > bound}
     assert not bad, bad
 
 
