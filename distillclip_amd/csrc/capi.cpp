@@ -12,7 +12,7 @@ void dclip_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int dclip_version(void) { return 2; }
+extern "C" int dclip_version(void) { return 3; }
 extern "C" const char* dclip_arch(void) { return "gfx950"; }
 extern "C" const char* dclip_last_error_string(void) { return g_err; }
 

@@ -6,8 +6,9 @@
  * nn.Module calls.  Each entry point cites the reference call site (file:line under the reference root) whose
  * arithmetic it implements.  All pointers are raw device pointers; `stream` is a hipStream_t passed as void*.
  * No allocation and no synchronisation inside any entry point, and no global mutable state on the compute path: the only
- * process-global state is the opt-in launch trace (dclip_trace_*, mutex-guarded, profiling only) and the tuning knobs read
- * from DCLIP_* environment variables, which are latched once on first use.  Every function returns
+ * process-global state is the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback
+ * counter) and the tuning knobs read from DCLIP_* environment variables, which are latched once on first use and constant
+ * afterwards.  Every function returns
  * 0 on success, DCLIP_EINVAL (-1) for a bad argument, DCLIP_ELAUNCH (-2) for a HIP launch failure, and
  * dclip_last_error_string() (thread-local) explains the last failure.
  *

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(l._dll, name), name
-    assert l.dclip_version() == 2 and l.dclip_arch() == b'gfx950'
+    assert l.dclip_version() == 3 and l.dclip_arch() == b'gfx950'
 
 
 def test_argument_validation_happens_on_host():
