@@ -664,8 +664,10 @@ constexpr int TN_LDS = (4 * TNB > 128 * TCLD * 4) ? 4 * TNB : 128 * TCLD * 4;
 
 __device__ __forceinline__ int tn_key(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
-__device__ __forceinline__ void tn_stage_glds(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, int cols, char* tile,
-                                              int wave, int lane) {
+// per-lane source pointers of this wave's four pieces of a k-major [64 x 128] operand tile at the slice's first chunk (the chunk
+// index adds a wave-uniform byte offset: no 64-bit multiply per piece and chunk — see tn_half_sources)
+__device__ __forceinline__ void tn_glds_sources(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, int cols, int wave, int lane,
+                                                const char* (&src)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int piece = wave * 4 + s;                 // 16 pieces of 4 rows
@@ -673,9 +675,13 @@ __device__ __forceinline__ void tn_stage_glds(const bf16_t* __restrict__ G, int6
         const int lc = (lane & 15) ^ tn_key(r);         // logical chunk that lands in physical chunk (lane & 15)
         int col = c0 + lc * 8;
         col = col < cols ? col : cols - 8;              // column edge: duplicate a valid chunk (those outputs are not stored)
-        const bf16_t* src = G + (int64_t)(m0 + r) * ld + col;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + piece * 1024), 16, 0, 0);
+        src[s] = (const char*)(G + (int64_t)(m0 + r) * ld + col);
     }
+}
+__device__ __forceinline__ void tn_stage_glds(const char* const (&src)[4], int64_t chunk_off, char* tile, int wave) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[s] + chunk_off), (lds_void*)(tile + (wave * 4 + s) * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int r0, int x0, int lane) {
@@ -714,14 +720,19 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    tn_stage_glds(p.A, p.lda, m_begin, p0, p.P, As, wave, lane);
-    tn_stage_glds(p.B, p.ldb, m_begin, q0, p.Q, Bs, wave, lane);
+    const char* src_a[4];
+    const char* src_b[4];
+    tn_glds_sources(p.A, p.lda, m_begin, p0, p.P, wave, lane, src_a);
+    tn_glds_sources(p.B, p.ldb, m_begin, q0, p.Q, wave, lane, src_b);
+    const int64_t step_a = (int64_t)TC * p.lda * 2, step_b = (int64_t)TC * p.ldb * 2;        // bytes per chunk (wave-uniform)
+    tn_stage_glds(src_a, 0, As, wave);
+    tn_stage_glds(src_b, 0, Bs, wave);
     for (int ct = 0; ct < nc; ++ct) {
         __syncthreads();
         if (ct + 1 < nc) {
             const int nb = (ct + 1) & 1;
-            tn_stage_glds(p.A, p.lda, m_begin + (ct + 1) * TC, p0, p.P, As + nb * TNB, wave, lane);
-            tn_stage_glds(p.B, p.ldb, m_begin + (ct + 1) * TC, q0, p.Q, Bs + nb * TNB, wave, lane);
+            tn_stage_glds(src_a, (ct + 1) * step_a, As + nb * TNB, wave);
+            tn_stage_glds(src_b, (ct + 1) * step_b, Bs + nb * TNB, wave);
         }
         const char* a_t = As + (ct & 1) * TNB;
         const char* b_t = Bs + (ct & 1) * TNB;
@@ -767,16 +778,24 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
 // slice of the token axis (long contraction = the regime this pipeline is best at); partial tiles are added with
 // row-contiguous f32 atomics staged through LDS.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, char* buf, int wave,
-                                              int lane) {
+// per-lane source pointers of this wave's two LDS-DMA pieces of a k-major half-tile at the slice's first chunk: the chunk index only
+// adds a wave-uniform byte offset.  (Formed per issue as G + (m0 + r) * ld + c, the compiler re-did the 64-bit multiply for every
+// piece: 16 v_mul_lo_u32 + 8 v_mad_u64_u32 — quarter-rate instructions — per wave and chunk, ~1 500 issue cycles per SIMD and chunk
+// next to 2 048 cycles of MFMA: the contraction loop ran 3 600 cycles per chunk where gemm_nt256_kernel's runs 2 465.)
+__device__ __forceinline__ void tn_half_sources(const bf16_t* __restrict__ G, int64_t ld, int m0, int c0, int wave, int lane,
+                                                const char* (&src)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int piece = wave * 2 + s;                 // 16 pieces of 4 rows per half-tile, 2 per wave
         const int r = piece * 4 + (lane >> 4);
         const int lc = (lane & 15) ^ tn_key(r);
-        const bf16_t* src = G + (int64_t)(m0 + r) * ld + c0 + lc * 8;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + piece * 1024), 16, 0, 0);
+        src[s] = (const char*)(G + (int64_t)(m0 + r) * ld + c0 + lc * 8);
     }
+}
+__device__ __forceinline__ void stage_half_tn(const char* const (&src)[2], int64_t chunk_off, char* buf, int wave) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[s] + chunk_off), (lds_void*)(buf + (wave * 2 + s) * 1024), 16, 0, 0);
 }
 
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
@@ -808,11 +827,20 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // half-tile l = 4*chunk + w ; w: 0 B_lo, 1 B_hi (X columns q0 + w*128), 2 A_lo, 3 A_hi (dY columns p0 + (w-2)*128)
+    const char* srcs[4][2];
+    tn_half_sources(p.B, p.ldb, m_begin, q0, wave, lane, srcs[0]);
+    tn_half_sources(p.B, p.ldb, m_begin, q0 + 128, wave, lane, srcs[1]);
+    tn_half_sources(p.A, p.lda, m_begin, p0, wave, lane, srcs[2]);
+    tn_half_sources(p.A, p.lda, m_begin, p0 + 128, wave, lane, srcs[3]);
+    const int64_t step_b = (int64_t)TC * p.ldb * 2, step_a = (int64_t)TC * p.lda * 2;      // bytes per chunk (wave-uniform)
     auto issue = [&](int l) {
         const int kt = l >> 2, w = l & 3;
         char* buf = smem + ((kt & 1) * 4 + w) * HT;
-        if (w < 2) stage_half_tn(p.B, p.ldb, m_begin + kt * TC, q0 + w * 128, buf, wave, lane);
-        else stage_half_tn(p.A, p.lda, m_begin + kt * TC, p0 + (w - 2) * 128, buf, wave, lane);
+        // (w is a compile-time constant at every call site once the loop body is unrolled: l = 4 * chunk + const)
+        if (w == 0) stage_half_tn(srcs[0], kt * step_b, buf, wave);
+        else if (w == 1) stage_half_tn(srcs[1], kt * step_b, buf, wave);
+        else if (w == 2) stage_half_tn(srcs[2], kt * step_a, buf, wave);
+        else stage_half_tn(srcs[3], kt * step_a, buf, wave);
     };
     auto stamp = [&](int k) {
         if (p.stamps && tid == 0) {
@@ -828,7 +856,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
     // are requested in phase A of chunk kt, the B halves of chunk kt + 2 in phase B); a wave retires its own LDS reads before
     // the phase's first barrier, so a region is only refilled once nobody reads it any more.
     const int npro = nload < 6 ? nload : 6;
-    for (int l = 0; l < npro; ++l) issue(l);
+#pragma unroll
+    for (int l = 0; l < 6; ++l)
+        if (l < npro) issue(l);          // (constant l: the source table stays in registers)
     if (nload > 4) WAIT_VMCNT(4); else WAIT_VMCNT(0);      // (two B halves of chunk 1 stay in flight: 2 instructions each)
     __builtin_amdgcn_s_barrier();
     stamp(1);
