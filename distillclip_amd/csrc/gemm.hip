@@ -695,6 +695,26 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int r0, int x0, 
     return u.v;
 }
 
+// The same fragment through inline asm, for gemm_tn256_kernel: hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 that follows an LDS-DMA in program order (it cannot tell that the read does not alias the
+// in-flight destination), which drained the six-half-tile load stream of that kernel TWICE per chunk — the counted vmcnt waits
+// below were dead letters.  An asm read is invisible to that pass; its completion is covered by the explicit lgkmcnt(0) before
+// each phase's barrier, fenced against the MFMAs by a sched_barrier (cdna_hip_programming.md section 5.4 rule 18).
+// base = LDS byte address of the fragment at contraction offset 0; OFF = rows * 256 (rows + 32 keep the swizzle key).
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_frag_asm(unsigned base) {
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s.lo) : "v"(base), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s.hi) : "v"(base), "n"(OFF + 4 * 256));
+    return u.v;
+}
+__device__ __forceinline__ unsigned tr_frag_base(const char* tile, int x0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = 8 * g + q;
+    const int chunk = (x0 >> 3) + (pp >> 1);
+    return (unsigned)(uintptr_t)(tile + row * 256 + ((chunk ^ tn_key(row)) << 4) + (pp & 1) * 8);
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -876,20 +896,21 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         const int k4 = kt * 4;
         // phase A : rows 0-63
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                b0[j][kb] = tr_frag_swz(bt, kb * 32, bcol + j * 16, lane);
-                b1[j][kb] = tr_frag_swz(bt, kb * 32, bcol + (2 + j) * 16, lane);
-            }
+        for (int j = 0; j < 2; ++j) {
+            const unsigned a0 = tr_frag_base(bt, bcol + j * 16, lane), a1 = tr_frag_base(bt, bcol + (2 + j) * 16, lane);
+            b0[j][0] = tr_frag_asm<0>(a0); b0[j][1] = tr_frag_asm<32 * 256>(a0);
+            b1[j][0] = tr_frag_asm<0>(a1); b1[j][1] = tr_frag_asm<32 * 256>(a1);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, i * 16, lane);
+        for (int i = 0; i < 4; ++i) {
+            const unsigned a0 = tr_frag_base(at, i * 16, lane);
+            af[i][0] = tr_frag_asm<0>(a0); af[i][1] = tr_frag_asm<32 * 256>(a0);
+        }
         if (k4 + 6 < nload) issue(k4 + 6);
         if (k4 + 7 < nload) issue(k4 + 7);
         WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -906,13 +927,16 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         // phase B : rows 64-127
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) af[i][kb] = tr_frag_swz(at, kb * 32, (4 + i) * 16, lane);
+        for (int i = 0; i < 4; ++i) {
+            const unsigned a0 = tr_frag_base(at, (4 + i) * 16, lane);
+            af[i][0] = tr_frag_asm<0>(a0); af[i][1] = tr_frag_asm<32 * 256>(a0);
+        }
         if (k4 + 8 < nload) { issue(k4 + 8); issue(k4 + 9); WAIT_VMCNT(4); }       // chunk kt + 1 landed
         else WAIT_VMCNT(0);
         WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
