@@ -756,19 +756,25 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTN p) {
         }
         const char* a_t = As + (ct & 1) * TNB;
         const char* b_t = Bs + (ct & 1) * TNB;
+        // (asm reads: behind the builtin form hipcc waits vmcnt(0) for the LDS-DMA of chunk ct + 1 just issued above, i.e. the
+        //  prefetch was drained before the chunk it was meant to overlap: tr_frag_asm)
+        unsigned abase[4], bbase[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 af[4], bfr[4];
+        for (int i = 0; i < 4; ++i) { abase[i] = tr_frag_base(a_t, wp * 64 + i * 16, lane); bbase[i] = tr_frag_base(b_t, wq * 64 + i * 16, lane); }
+        bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tr_frag_swz(a_t, kb * 32, wp * 64 + i * 16, lane);
+        for (int i = 0; i < 4; ++i) { af[0][i] = tr_frag_asm<0>(abase[i]); bfr[0][i] = tr_frag_asm<0>(bbase[i]); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = tr_frag_swz(b_t, kb * 32, wq * 64 + j * 16, lane);
+        for (int i = 0; i < 4; ++i) { af[1][i] = tr_frag_asm<32 * 256>(abase[i]); bfr[1][i] = tr_frag_asm<32 * 256>(bbase[i]); }
+        WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][i], bfr[kb][j], acc[i][j], 0, 0, 0);
     }
     // epilogue: stage the 128x128 f32 tile through LDS (operand buffers are dead) so that every atomic wave-instruction
     // adds 64 consecutive floats of one output row = 256 contiguous bytes (the full-rate shape, MI355X_MICROARCH.md
