@@ -18,11 +18,24 @@ import mfma_hazard as H                                             # noqa: E402
 SO = os.path.join(ROOT, 'distillclip_amd', 'libdistillclip_hip.so')
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=1)
+def _disassembly():
+    return H.disassemble_so(SO)
+
+
+@functools.lru_cache(maxsize=1)
+def _parsed():
+    return H.parse(_disassembly())
+
+
 @pytest.fixture(scope='module')
 def shipped():
     if not os.path.exists(SO):
         pytest.skip('library not built')
-    return H.check_text(H.disassemble_so(SO))
+    return H.check_text(_disassembly())
 
 
 def test_checker_flags_the_pre_fix_object():
@@ -76,3 +89,61 @@ def test_forward_score_stage_baseline(shipped):
     fam = _family(shipped, 'attn_mix_fwd_kernel')
     total = sum(len(v['valu_built']) for v in fam.values())
     assert total <= 200, total
+
+
+# ---- round 4: two more properties of the shipped code object that the source cannot guarantee by itself -------------------------------
+def _kernels_text(name_part):
+    """{demangled name: [instruction text]} of the shipped kernels whose name contains name_part (llvm-objdump order)"""
+    import re
+    out = {}
+    for name, (insns, _labels) in _parsed().items():
+        dn = H.demangle(name)
+        if name_part in dn:
+            out[dn] = [x.text for x in insns]
+    return out
+
+
+@pytest.mark.parametrize('kernel', ['gemm_tn256_kernel', 'gemm_tn_glds_kernel', 'gemm_nt256_kernel<0, false, 10>', 'gemm_nt256_kernel<0, true, 8>'])
+def test_no_queue_drain_in_front_of_lds_reads(kernel):
+    """hipcc puts `s_waitcnt vmcnt(0)` in front of an LDS read it cannot prove disjoint from an in-flight LDS-DMA (it did for the
+    ds_read_tr builtins of the wgrad kernels: the LDS-DMA look-ahead was drained twice per chunk).  No hot GEMM loop
+    may wait for the whole vector-memory queue directly in front of a ds_read."""
+    if not os.path.exists(SO):
+        pytest.skip('library not built')
+    ks = _kernels_text(kernel)
+    assert ks, kernel
+    for dn, ins in ks.items():
+        assert any(t.startswith('global_load_lds') for t in ins), dn
+        bad = [(a, b) for a, b in zip(ins, ins[1:]) if a.startswith('s_waitcnt') and 'vmcnt(0)' in a and b.startswith('ds_read')]
+        assert not bad, (dn, bad[:2])
+
+
+@pytest.mark.parametrize('kernel', ['gemm_tn256_kernel', 'gemm_tn_glds_kernel'])
+def test_asm_lds_reads_are_not_consumed_before_their_wait(kernel):
+    """the transposing LDS reads of the wgrad kernels are inline asm (invisible to hipcc's wait-count pass): nothing may read their
+    destination registers before the next `s_waitcnt lgkmcnt(0)` — a compiler copy or spill of such a register would move garbage"""
+    import re
+    if not os.path.exists(SO):
+        pytest.skip('library not built')
+    for dn, ins in _kernels_text(kernel).items():
+        pending, n_reads = set(), 0
+        for t in ins:
+            op = t.split()[0]
+            if op == 'ds_read_b64_tr_b16':
+                m = re.search(r'v\[(\d+):(\d+)\]', t)
+                pending.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                n_reads += 1
+                continue
+            if op == 's_waitcnt' and 'lgkmcnt(0)' in t:
+                pending = set()
+                continue
+            if pending:
+                ops = t.split(None, 1)[1] if ' ' in t else ''
+                parts = [x.strip() for x in ops.split(',')]
+                srcs = parts if op.startswith(('global_store', 'ds_write', 'global_load_lds', 'buffer_store')) else parts[1:]
+                used = set()
+                for part in srcs:
+                    for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', part):
+                        used.update(range(int(m.group(1)), int(m.group(2)) + 1) if m.group(1) else [int(m.group(3))])
+                assert not (used & pending), (dn, t)
+        assert n_reads >= 32, (dn, n_reads)
