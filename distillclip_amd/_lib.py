@@ -52,6 +52,11 @@ class _Lib:
             raise ImportError(
                 f'{_LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 f'(or `make -C distillclip_amd/csrc`).  distillclip_amd has no CPU fallback.')
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so): it must be in the process BEFORE this library is mapped, or the
+        # loader resolves our libamdhip64 dependency to /opt/rocm's copy and the process ends up with two runtimes — kernels of this
+        # library then fail with "no ROCm-capable device is detected" (seen with `python __graft_entry__.py smoke`, which loaded the
+        # library in build() before anything had imported torch)
+        import torch                                # noqa: F401
         self._dll = ctypes.CDLL(_LIB_PATH)
         self.protos = _parse_header()
         for name, (res, args) in self.protos.items():
