@@ -136,3 +136,25 @@ def test_checkpoint_version_is_parseable():
     from packaging.version import Version
     from distillclip_amd import checkpoint
     assert Version(checkpoint.LIGHTNING_VERSION) < Version('2.0')
+
+
+def test_parameter_gradients_travel_through_autograd_only_when_an_outer_wrapper_owns_the_exchange(monkeypatch):
+    """DCLIP_DP_MODE=off (torch DistributedDataParallel / Lightning's ddp strategy reduces the gradients) switches the towers to
+    returning parameter gradients to autograd, so the reducer's hooks fire; every other mode writes p.grad directly (the fused optimizer
+    and the built-in exchange read the flat buffers).  A per-tower override wins over the environment."""
+    from distillclip_amd.model.component._tower import autograd_params_mode
+
+    class T:
+        pass
+    t = T()
+    monkeypatch.delenv('DCLIP_DP_MODE', raising=False)
+    assert autograd_params_mode(t) is False
+    for mode, want in (('off', True), ('allreduce', False), ('reduce_scatter', False)):
+        monkeypatch.setenv('DCLIP_DP_MODE', mode)
+        assert autograd_params_mode(t) is want, mode
+    monkeypatch.setenv('DCLIP_DP_MODE', 'off')
+    t.autograd_params = False
+    assert autograd_params_mode(t) is False
+    monkeypatch.delenv('DCLIP_DP_MODE')
+    t.autograd_params = True
+    assert autograd_params_mode(t) is True
