@@ -1242,8 +1242,11 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.clk = nullptr;
     if (g_clock_buf && g_clock_cap > 0) p.clk = g_clock_buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % g_clock_cap);
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes of the call: both operands once, the output once, plus what the fused epilogue consumes / produces — the f32 residual
+    // it adds (read), the saved pre-activation / derivative it multiplies by (aux_in) or stores (aux_out); round 3 counted operands + output only
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
-                  2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N, stream, (int)M, (int)N, (int)K,
+                  2.0 * ((double)M * K + (double)N * K) + ((out_f32 ? 4.0 : 2.0) + (residual ? 4.0 : 0.0) + (aux_in ? 2.0 : 0.0) + (aux_out ? 2.0 : 0.0)) * (double)M * N,
+                  stream, (int)M, (int)N, (int)K,
                   act + 8 * (out_f32 != 0) + 16 * (residual != nullptr) + 32 * (colsum_acc != nullptr));
     switch (act) {
         case 0: return launch_nt<0>(p, out_f32 != 0, st);

@@ -234,7 +234,8 @@ class GradSync:
                 if sp is not None and sp['bucket'] == i:
                     tw._sparse = None                   # (a step marked dense by note_token_ids: the whole bucket travels and is cleared)
                 reduce_scatter_avg(tw.gshard[off:off + (o1 - o0)], g[b0:b1], group=self.group_for(tw))
-                g[b0:b1].zero_()                        # the backward accumulates (+=): leave the bucket clean for the next step
+                # (the backward accumulates (+=): the exchanged buffer is cleared ONCE, behind the last bucket's collective, in finish() —
+                #  ten fills per tower and step before)
 
     # ---- row-sparse exchange of the token-embedding gradient (reference weight_share_model.py:407) ----
     def note_token_ids(self, tw, ids):
@@ -359,7 +360,6 @@ class GradSync:
             start = lo - (t0 + r_lo * D)
             shard[lo - o0:hi - o0].copy_(buf.view(-1)[start:start + (hi - lo)])
         touched = uniq[:max(cuts)]                       # the union (the segments cover every table row of the bucket)
-        table.index_fill_(0, touched, 0.0)               # the backward accumulates (+=): touched rows clean for the next step
         # the rest of the bucket (positional embedding, ...) is small and dense
         for a, e in ((b0, t0), (t1, b1)):
             if a < e:
@@ -368,7 +368,6 @@ class GradSync:
                 x0, x1 = max(a, o0), min(e, o1)
                 if x0 < x1:
                     shard[x0 - o0:x1 - o0].copy_(g[x0:x1])
-                rest.zero_()
         tw.sparse_rows_last = int(touched.numel())       # (diagnostics / tests: rows exchanged instead of V)
         tw.sparse_segment_rows_last = mseg               # rows per destination rank in the padded collective
 
@@ -378,6 +377,10 @@ class GradSync:
             self.bucket_ready(tw, i, after=getattr(tw, 'bwd_done', None))
         tw.dp_released = 0
         s = self._streams.get(self._key(tw))
+        # every bucket has been handed to its collective on the exchange stream: clear the whole gradient buffer behind them, once
+        # (the next backward of this tower is ordered after this stream through the optimizer's opt_done / grads_ready events)
+        with GradSync._On(s if tw.flat_grad.is_cuda else None):
+            tw.flat_grad.zero_()
         if tw.flat_grad.is_cuda and s is not None:
             done = torch.cuda.Event()
             done.record(s)
