@@ -7,6 +7,38 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _to_numpy(o):
+    if isinstance(o, torch.Tensor):
+        return ('__tensor__', o.detach().cpu().numpy().copy())
+    if isinstance(o, dict):
+        return {k: _to_numpy(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_numpy(v) for v in o)
+    return o
+
+
+def _to_torch(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == '__tensor__':
+        return torch.from_numpy(o[1])
+    if isinstance(o, dict):
+        return {k: _to_torch(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_torch(v) for v in o)
+    return o
+
+
+class _ResultQueue:
+    """what the ranks report through: tensors travel as numpy arrays by value.  (A torch tensor on a multiprocessing queue is a
+    shared-memory handle served by the SENDING process; a rank that had already exited when the parent unpickled its report made
+    the test fail with FileNotFoundError under load.)"""
+
+    def __init__(self, q):
+        self.q = q
+
+    def put(self, item):
+        self.q.put(_to_numpy(item))
+
+
 def _run_ranks(target, world=2, timeout=120):
     """spawn `world` rank processes of `target(rank, world, rdzv, q)` and collect one queue item per rank.  Rendezvous is a
     FileStore in a private temporary directory: no port is picked, so there is no bind-then-close race and NO retry -- a queue
@@ -17,12 +49,12 @@ def _run_ranks(target, world=2, timeout=120):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     d = tempfile.mkdtemp(prefix='dclip_rdzv_')
-    ps = [ctx.Process(target=target, args=(r, world, os.path.join(d, 'store'), q)) for r in range(world)]
+    ps = [ctx.Process(target=target, args=(r, world, os.path.join(d, 'store'), _ResultQueue(q))) for r in range(world)]
     for p in ps:
         p.start()
     try:
         try:
-            res = [q.get(timeout=timeout) for _ in ps]
+            res = [_to_torch(q.get(timeout=timeout)) for _ in ps]
         except _queue.Empty:
             raise AssertionError(f'ranks did not report within {timeout} s (exit codes so far {[p.exitcode for p in ps]})')
         codes = []
