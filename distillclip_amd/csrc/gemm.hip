@@ -10,6 +10,8 @@
 // st_16x32 XOR swizzle (byte ^= ((byte >> 9) & 1) << 5) applied on the SOURCE address and again on the
 // ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
 
+#include <mutex>
+#include <unordered_map>
 #include "gemm_common.h"
 #include <atomic>
 
@@ -283,6 +285,36 @@ __device__ __forceinline__ void stage_rowhalf(const bf16_t* __restrict__ G, int6
 // MI = 16-row MFMA tiles per wave along M: 8 -> the 256 x 256 tile, 10 -> a 320 x 256 tile.  The taller tile exists for wave
 // quantisation: a [25600, 768] output is 300 tiles of 256^2 (two rounds on 256 CUs, the second 17 % full) but 240 tiles of
 // 320 x 256 (one round); [39424, 512] is 308 against 248.  launch_nt picks the variant with the smaller rounds x tile-work.
+// sum over the 16 lanes of a DPP row (= the 16 rows a lane group holds of one output column), in every lane of the row: quad swaps,
+// then the half-row and row mirrors.  VALU only: no LDS round trip per step and no lane index (ds_bpermute addresses kept the lane
+// id alive through the tile loop, spilled, and its reload put an s_waitcnt vmcnt(0) — every store of the tile — in front of the sums)
+__device__ __forceinline__ float row16_sum(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});     // quad_perm [1, 0, 3, 2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});     // quad_perm [2, 3, 0, 1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});    // row_mirror
+    return x;
+}
+
+constexpr bool nt256_persistent(int act, bool out_f32) { return !out_f32 && act != 3 && act != 4; }
+
+// ticket counters of the persistent launches: 8 (one per XCD chunk, 128 B apart) per stream — launches of one stream run one after
+// another and every launch leaves its counters at zero, launches of different streams overlap.  Zeroed once, on the stream itself.
+unsigned* nt256_tile_counters(hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, unsigned*> per_stream;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_stream.find(st);
+    if (it != per_stream.end()) return it->second;
+    unsigned* c = nullptr;
+    if (hipMalloc((void**)&c, 8 * 128) != hipSuccess || hipMemsetAsync(c, 0, 8 * 128, st) != hipSuccess) c = nullptr;
+    per_stream[st] = c;                                  // (null: the launches of this stream walk their tiles statically)
+    return c;
+}
+
 template <int ACT, bool OUT_F32, int MI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,33 +331,57 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // tiles the 32 concurrent tiles of an XCD span every B panel (N = 3072, K = 768: 4.7 MB, more than the 4 MB L2), so B is
     // re-streamed from beyond L2 once per round; with a group whose B panels stay L2-resident an XCD streams its A rows once
     // per group and reads B once (host-side choice and traffic model: launch_nt).
+    // Persistent launches (gridDim.x < tiles, a multiple of 8): workgroup b starts with tile b and then DRAWS its next tiles from
+    // the ticket counter of its XCD's chunk (b & 7), i.e. in the order the hardware dispatcher would have handed them out — a static
+    // b, b + grid, ... walk lets the slowest workgroup's six tiles set the launch time (39424 x 3072 x 768: -5 %).  The operands of the
+    // NEXT tile's first K-tile and a half are requested when the epilogue of the current one starts (the LDS ring is idle from the
+    // main loop's last barrier on), so that only the first tile of a workgroup pays the ~3.5 k cycles of HBM latency in front of its
+    // main loop.  The ticket for tile i + 1 is drawn at the top of tile i (one lane, returning atomic, in front of the wait that
+    // opens the main loop) and handed to the other waves through an LDS word behind the operand ring.
+    // Compiled in for the bf16 epilogues without side operands only: the tile loop keeps the operand descriptors live through the
+    // epilogue, and the f32 / DGELU / MULAUX epilogues have neither the scalar nor the vector registers for that (77 spilled SGPRs and
+    // 90-255 spilled VGPRs when tried) — their launches in the step are single-round anyway (N = 512 / 768) or dominated by an
+    // HBM-bound epilogue.
+    constexpr bool PERSIST = nt256_persistent(ACT, OUT_F32);
     const int nwg = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    int tm, tn;
-    if (p.group_n >= p.tiles_n) { tm = t / p.tiles_n; tn = t % p.tiles_n; }
-    else {
-        const int per = p.tiles_m * p.group_n;
-        const int gi = t / per, rem = t - gi * per;
-        const int left = p.tiles_n - gi * p.group_n;
-        const int gw = left < p.group_n ? left : p.group_n;
-        tm = rem / gw; tn = gi * p.group_n + rem % gw;
-    }
-    const int m0 = tm * BMT, n0 = tn * 256;
     const int nk = p.K / BK;
     const int nload = 4 * nk;
+    int m0, n0;
+    auto locate = [&](int tl) {
+        const int t = xcd_remap(tl, nwg);
+        int tm, tn;
+        if (p.group_n >= p.tiles_n) { tm = t / p.tiles_n; tn = t % p.tiles_n; }
+        else {
+            const int per = p.tiles_m * p.group_n;
+            const int gi = t / per, rem = t - gi * per;
+            const int left = p.tiles_n - gi * p.group_n;
+            const int gw = left < p.group_n ? left : p.group_n;
+            tm = rem / gw; tn = gi * p.group_n + rem % gw;
+        }
+        m0 = tm * BMT; n0 = tn * 256;
+    };
+    locate(blockIdx.x);
+    // chunk of this workgroup's XCD (xcd_remap): `chunk` tiles, the launch's grid / 8 workgroups start on its first positions
+    const int xme = blockIdx.x & 7;
+    const int chunk = (nwg >> 3) + (xme < (nwg & 7) ? 1 : 0);
+    const int first_free = (int)gridDim.x >> 3;
+    unsigned* const ctr = PERSIST && p.tile_ctr && (int)gridDim.x < nwg ? p.tile_ctr + xme * 32 : nullptr;
+    int* const next_word = (int*)(smem + 2 * PAR);          // LDS word behind the ring: position of the next tile in the chunk
+    int pos = blockIdx.x >> 3;                              // position of the current tile in the chunk
+    int tiles_done = 0;
 
     f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_up (upper row tiles of both wave groups), 3 A_dn (lower row tiles)
+    // ln: the lane index, re-issued as an opaque value at the top of every tile and of every epilogue, so that hipcc neither hoists
+    // the per-lane address arithmetic of one phase out of the tile loop nor carries it through the other phase: the main loop and
+    // the f32 epilogues each fill the 256 registers on their own (89-307 spills with a plain `lane`)
+    int ln = lane;
     auto issue = [&](int l) {
         const int tile = l >> 2, w = l & 3;
         char* par = smem + (tile & 1) * PAR;
-        if (w < 2) stage_half_perm(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, lane);
-        else stage_rowhalf<RH>(p.A, p.lda, m0, p.M, tile * BK, par + 2 * HT, HTA, w - 2, wave, lane);
+        if (w < 2) stage_half_perm(p.B, p.ldb, n0 + w * 128, p.N, tile * BK, par + w * HT, wave, ln);
+        else stage_rowhalf<RH>(p.A, p.lda, m0, p.M, tile * BK, par + 2 * HT, HTA, w - 2, wave, ln);
     };
     // profiling stamps (off unless dclip_trace_gemm_stamps armed them): s_memtime at start / first operands landed / main loop
     // done / epilogue done (stores acknowledged), s_memrealtime at start / end
@@ -343,15 +399,42 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // until half-tile X has landed" = vmcnt(number of instructions issued after X)
 #define WAIT_VM2(n8, n10) do { if (MI == 10) WAIT_VMCNT(n10); else WAIT_VMCNT(n8); } while (0)
     const int npro = nload < 7 ? nload : 7;                // tile 0 entirely, tile 1: B_lo, B_hi, A_up
+    // ticket for the second tile: OLDER than the first tile's requests, so that their counted wait below covers it.  (The atomic is
+    // hidden from hipcc's wait-count pass; an extra entry in the in-order queue only makes the counted waits stricter, never laxer.)
+    unsigned ticket = 0;
+    auto draw = [&]() {
+        if (PERSIST && ctr && tid == 0)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr), "v"(1u) : "memory");
+    };
+    draw();
     for (int l = 0; l < npro; ++l) issue(l);
-    if (nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);    // B_lo, B_hi, A_up of tile 0 landed (younger: A_dn(0), B, B, A_up(1))
+    const int a_off = 2 * HT + wr * HTA;                     // this wave's A half
+    const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
+  for (bool first = true;; first = false) {
+    if (!first) draw();                                    // (next tile's ticket; the wait below is vmcnt(0) for every later tile)
+    ln = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(ln));
+    const int fragoff = swz((ln & 15) * 64 + (ln >> 4) * 16);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // first tile: B_lo, B_hi, A_up of K-tile 0 landed (younger: A_dn(0), B, B, A_up(1)).  Later tiles: their requests went out
+    // before the previous epilogue's stores; vmcnt retires in issue order and the loop below counts LDS-DMA instructions only, so
+    // everything older (those stores included) has to be acknowledged before it starts
+    if (first && nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);
+    if (PERSIST && ctr) {
+        if (tid == 0) {
+            asm volatile("" : "+v"(ticket));                  // (the value is there: older than everything the wait above lets pend)
+            *next_word = first_free + (int)ticket;
+            if ((int)ticket == chunk - 1) *ctr = 0u;          // the chunk's last ticket (every workgroup draws until it misses): re-arm
+        }
+        WAIT_LGKM0();
+    }
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
 
-    const int fragoff = swz((lane & 15) * 64 + (lane >> 4) * 16);
-    const int a_off = 2 * HT + wr * HTA;                     // this wave's A half
-    const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
     bf16x8 af[RH][2], b0[2][2], b1[2][2];
 
     // Two phases per K-tile: A = upper row tiles of the wave x all four column tiles, B = lower row tiles.  MFMA clusters of
@@ -428,13 +511,28 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     //  object — tools/asm/mfma_hazard.py, tests/test_mfma_hazard_cpu.py — shows that no VALU instruction of the epilogue writes a
     //  fragment register within 12 slots of the MFMAs that read it, and keeps showing it: the padding is gone)
     stamp(2);
+    // the next tile of a persistent workgroup: its first operands are requested now, behind nothing but this tile's side loads
+    // (the column-sum tail of the epilogue goes through LDS: those launches request at the very end instead)
+    const int m0c = m0, n0c = n0;                          // this tile; m0 / n0 move on with the requests
+    int nextpos = pos + first_free;                        // static walk without a counter
+    if (PERSIST && ctr) nextpos = __builtin_amdgcn_readfirstlane(*(volatile int*)next_word);
+    // (walk: this launch has fewer workgroups than tiles; `tiles_done` bounds the loop whatever the counter returns)
+    const bool more = PERSIST && (int)gridDim.x < nwg && nextpos < chunk && nextpos > pos && ++tiles_done < chunk;
+    const bool early = more && !p.colsum;
+    ln = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(ln));
+    if (early) {
+        locate(nextpos * 8 + xme);
+#pragma unroll 1
+        for (int l = 0; l < npro; ++l) { issue(l); __builtin_amdgcn_sched_barrier(0); }   // (one request's addresses at a time: the accumulators are live)
+    }
+    const int g = ln >> 4, rl = ln & 15;
 
     // epilogue, straight from registers (see stage_half_perm): lane (g, c) owns row c of every row tile i and, per column pair
     // jp, 8 consecutive columns.  No LDS, no barrier: a wave starts storing as soon as its own accumulators are final.  Side
     // operands (the f32 residual, which may alias C in place, and the aux rows of the DGELU / MULAUX variants) of row tile
     // i + 1 are requested before the stores of row tile i are issued, so that their in-order vmcnt wait never includes a store.
-    const int g = lane >> 4, rl = lane & 15;
-    const int colb = n0 + wc * 64 + g * 8;
+    const int colb = n0c + wc * 64 + g * 8;
     float bias[2][8], csum[2][8];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -457,13 +555,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : (MI == 6 ? 6 : 5))) : (MI == 10 ? 10 : NU));
     static_assert(NU % BU == 0, "batch size must divide the unit count");
     EpiSide side[SIDE ? BU : 1];
-    const int row0 = m0 + wr * AROWS + rl;
+    const int row0 = m0c + wr * AROWS + rl;
     const int64_t o0 = (int64_t)row0 * p.ldc + colb, r0off = (int64_t)row0 * p.ldr + colb;
     const int64_t ostep = 16 * p.ldc, rstep = 16 * p.ldr;
     // full: the tile lies inside the matrix (all but the last row / column of tiles) — the per-unit bounds test is then one scalar
     // branch instead of two vector compares and an exec-mask update.  (Compiled out entirely, the 2 MI units become one basic block
     // whose addresses and conversions are all hoisted to the top: 100-240 spilled registers.)
-    const bool full = m0 + BMT <= p.M && n0 + 256 <= p.N;
+    const bool full = m0c + BMT <= p.M && n0c + 256 <= p.N;
     auto run_units = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
@@ -512,14 +610,23 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = csum[jp][e];
-                x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+                const float x = row16_sum(csum[jp][e]);
                 if (rl == 0) cs[wr * 256 + wc * 64 + jp * 32 + g * 8 + e] = x;
             }
         WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if (tid < 256 && n0 + tid < p.N) unsafeAtomicAdd(p.colsum + n0 + tid, cs[tid] + cs[256 + tid]);
+        const int tc = wave * 64 + ln;              // (= tid, from the epilogue's opaque lane index: nothing hoisted out of the tile loop)
+        if (tc < 256 && n0c + tc < p.N) unsafeAtomicAdd(p.colsum + n0c + tc, cs[tc] + cs[256 + tc]);
     }
+    if (more && !early) {
+        __builtin_amdgcn_s_barrier();                      // every wave is done with the column sums' LDS words
+        locate(nextpos * 8 + xme);
+#pragma unroll 1
+        for (int l = 0; l < npro; ++l) { issue(l); __builtin_amdgcn_sched_barrier(0); }   // (one request's addresses at a time: the accumulators are live)
+    }
+    if (!more) break;
+    pos = nextpos;
+  }
     stamp(3);
     if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -1156,7 +1263,13 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
             tm = (p.M + mi * 32 - 1) / (mi * 32);
         }
         p.tiles_m = tm; p.tiles_n = tn;
-        const int grid256 = p.tiles_m * p.tiles_n;
+        // persistent launch: at most one workgroup per CU, each walking tiles b, b + grid, ... with the next tile's first operands
+        // requested under the current epilogue (DCLIP_GEMM_PERSIST=0: one workgroup per tile, =N: N workgroups, rounded to 8)
+        static const int persist = [] { const char* e = getenv("DCLIP_GEMM_PERSIST"); const int v = e ? atoi(e) : 1; return v == 1 ? 256 : (v & ~7); }();
+        const int ntiles = p.tiles_m * p.tiles_n;
+        const int grid256 = persist > 0 && ntiles > persist && nt256_persistent(ACT, out_f32) ? persist : ntiles;
+        static const int tickets = [] { const char* e = getenv("DCLIP_GEMM_TICKETS"); return e ? atoi(e) : 1; }();
+        p.tile_ctr = grid256 < ntiles && tickets ? nt256_tile_counters(st) : nullptr;
         // raster group width: minimise the modelled operand bytes from beyond L2 —  A once per group, B once per XCD while a
         // group's B panels (256 x K bf16 each) fit ~2.5 MB of the XCD's 4 MB L2, else once per round of 32 tiles per XCD
         {
@@ -1173,18 +1286,18 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
             p.group_n = force_g > 0 ? force_g : best_g;
         }
         if (mi == 10) {
-            const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2);
+            const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2) + 16;
             if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         if (mi == 6) {
-            const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2);
+            const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2) + 16;
             if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 6>), dim3(grid256), dim3(512), lds192, st, p);
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6>), dim3(grid256), dim3(512), lds192, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
-        const size_t lds256 = 8 * HT;
+        const size_t lds256 = 8 * HT + 16;
         if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 8>), dim3(grid256), dim3(512), lds256, st, p);
         else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8>), dim3(grid256), dim3(512), lds256, st, p);
         if (!has_rest) return dclip_check_launch("dclip_gemm_nt");
@@ -1239,6 +1352,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
     p.duo_prio = 0;
+    p.tile_ctr = nullptr;
     p.clk = nullptr;
     if (g_clock_buf && g_clock_cap > 0) p.clk = g_clock_buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % g_clock_cap);
     hipStream_t st = (hipStream_t)stream;

@@ -28,6 +28,8 @@ struct GemmNT {
     int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
     unsigned long long* clk;                        // measurement only (dclip_trace_gemm_clock): 4 x u64 of this launch, else null
     int duo_prio;                                   // gemm_duo.hip: how a workgroup picks its priority against its CU neighbour
+    unsigned* tile_ctr;                             // persistent 256-/320-row launches: 8 ticket counters (one per XCD chunk, 128 B apart,
+                                                    // zero between launches: the last ticket of a chunk resets its counter), else null
 };
 
 __device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }

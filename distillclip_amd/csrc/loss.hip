@@ -14,6 +14,7 @@
 // Cosine logits are bounded by 1, so softmax uses the fixed maximum 1/tau and row/column sums are plain additions.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -21,7 +22,7 @@ constexpr int SC_IMG = 0;      // +0 l1  +1 cos  +2 kl  +3 ce        (raw sums, 
 constexpr int SC_TXT = 4;
 constexpr int SC_POS = 8, SC_NEG = 9, SC_MSE = 10, SC_DIAG = 11, SC_KL0 = 12, SC_KL1 = 13, SC_LSE0 = 14, SC_LSE1 = 15;
 constexpr int NSC = 16;
-// The scalar accumulators are replicated: every wave adds to the copy picked by its block / wave index, loss_total_kernel sums
+// The scalar accumulators are replicated: every wave adds to the copy picked by its block / wave index, loss_write_total sums
 // the copies.  All of them in ONE cache line meant ~2 000 (row kernel) / ~4 000 (stripe kernel) serialised same-line atomics:
 // 33 and 67 us of kernels whose work is a few microseconds, on the step's critical path between forward and backward.
 constexpr int NREP = 64, SCSTRIDE = 32;                     // 64 copies, one 128-byte line each
@@ -44,7 +45,12 @@ struct LossArgs {
     float* stats_out;                         // row-block pass-A-only call: [6][Bl] slice-summed statistics for that gather
     int zs;                                   // column slices of the stripe kernels (blockIdx.z): fills the chip at B = 512
     float* dsh[2];                            // d loss / d normalised student embedding [zs][B,E] (partials per slice)
-    float* scal;                              // [NSC] atomically accumulated
+    float* scal;                              // [NREP][SCSTRIDE] atomically accumulated (replicated, see NREP)
+    unsigned* arrive;                         // arrival counters, zeroed with `scal` by the one fill of a call: [0] workgroups of the
+                                              // call's last kernel, [1 + dir * ceil(Bl / 16) + stripe] column slices of a stripe
+    int final_in_rows;                        // no cross-modal term: loss_rows_kernel is the last kernel
+    int fuse;                                 // 1: the follow-up work (normalisation backward, the 16 scalars) is done by last-arriving
+                                              // workgroups of the call's last kernel instead of by launches of their own (see last_arriver)
     float* out;                               // [16] user-visible scalars
     int B, E;                                 // B: number of columns = rows of the (gathered) inputs
     int r0, Bl;                               // the rows this call owns: [r0, r0 + Bl) (whole matrix: 0, B).  Row-block mode:
@@ -57,12 +63,31 @@ __device__ __forceinline__ float* scal_slot(const LossArgs& a) {
     return a.scal + r * SCSTRIDE;
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// "last arriver" hand-over inside ONE launch (no spinning, nobody waits): every workgroup publishes what it wrote
+// (agent-scope release fence), then adds one to a counter; the workgroup that draws the last ticket knows that all the
+// others' results are visible after its own acquire fence and does the follow-up work that used to be a separate launch
+// (round 3: loss_finalize_kernel after loss_stripe_b_kernel, loss_total_kernel after everything).  The follow-up reads in a fixed
+// order, so the results stay run-to-run identical whichever workgroup happens to be last.
+// -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool last_arriver(unsigned* counter, unsigned expected) {
+    __shared__ unsigned ticket;
+    __threadfence();                                        // release: this thread's stores and atomics, agent scope
+    __syncthreads();                                        // ... of every thread of the workgroup
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = ticket == expected - 1;
+    if (last) __threadfence();                              // acquire
+    return last;
+}
+
+__device__ void loss_write_total(const LossArgs& a);
 
 // -------------------------------------------------------------------------------------------------------------
 // kernel 1: one wave per sample: tower terms (+ their gradients) and the normalised embeddings
 // -------------------------------------------------------------------------------------------------------------
 template <int NV>   // float4 chunks per lane, E <= 256 * NV
-__global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
+__device__ __forceinline__ void loss_rows_body(const LossArgs& a) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.B) return;
@@ -162,6 +187,13 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
+    loss_rows_body<NV>(a);
+    // without cross-modal terms this is the call's only kernel: whoever finishes last writes the 16 scalars
+    if (a.final_in_rows && a.fuse && last_arriver(a.arrive, gridDim.x)) loss_write_total(a);
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // stripe kernels.  Tile of X = Xa[rows] . Xb[cols]^T on v_mfma_f32_16x16x4_f32.  The contraction index is permuted
 // so that a lane reads float4s: lane (r = l&15, g = l>>4) covers k = 16*o + 4*g + t at MFMA step t.
@@ -244,6 +276,35 @@ __global__ __launch_bounds__(256) void loss_stripe_a_kernel(LossArgs a) {
             const float v = (red[0][r][k] + red[1][r][k]) + (red[2][r][k] + red[3][r][k]);
             a.stats[((int64_t)z * 6 + dir * 3 + k) * a.Bl + i0 - a.r0 + r] = v;
         }
+    }
+}
+
+// normalisation backward of one owned row (local index b) of tower `tow`, by one wave:  x_hat = x / |x|  =>
+// dx = (g - x_hat (x_hat . g)) / |x|, added to the tower-term gradient.  g = the column slices' partial rows, added in slice order.
+__device__ __forceinline__ void loss_finalize_row(const LossArgs& a, int tow, int b, int lane) {
+    const float* xh = a.nrm[tow] + (int64_t)(a.r0 + b) * a.E;
+    float* g = a.dsh[tow] + (int64_t)b * a.E;
+    const int64_t zstride = (int64_t)a.Bl * a.E;
+    float dot = 0.f;
+    for (int c = lane * 4; c < a.E; c += 256) {
+        float4 y = *(const float4*)(g + c);
+        for (int zz = 1; zz < a.zs; ++zz) {                     // slice order: deterministic
+            const float4 p = *(const float4*)(g + zz * zstride + c);
+            y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
+        }
+        *(float4*)(g + c) = y;                                  // slice 0 now holds the complete row
+        const float4 x = *(const float4*)(xh + c);
+        dot += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    dot = wave_sum(dot);
+    const float inv = a.inv[tow][b];
+    float* d = a.ds[tow] + (int64_t)b * a.E;
+    for (int c = lane * 4; c < a.E; c += 256) {
+        const float4 x = *(const float4*)(xh + c), y = *(const float4*)(g + c);
+        float4 o = *(const float4*)(d + c);
+        o.x += (y.x - x.x * dot) * inv; o.y += (y.y - x.y * dot) * inv;
+        o.z += (y.z - x.z * dot) * inv; o.w += (y.w - x.w * dot) * inv;
+        *(float4*)(d + c) = o;
     }
 }
 
@@ -330,7 +391,7 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
         unsafeAtomicAdd(scal_slot(a) + (dir ? SC_LSE1 : SC_LSE0), __logf(grow ? grow[i0 + lane] : stat(rst, i0 - a.r0 + lane)) + 1.f);
     __syncthreads();
     // gradient rows: G[16, E] = dS_stripe[16, B] @ Y[B, E],  Y = normalised student embedding of the other modality
-    // (this slice's columns only: the slices' partial rows are added in loss_finalize_kernel)
+    // (this slice's columns only: the slices' partial rows are added by the stripe's last-arriving slice, loss_finalize_row)
     const float* Y = sb;
     float* G = a.dsh[dir] + (int64_t)z * Bl * E;
     const float* arow = dsl + (lane & 15) * ldl + (lane >> 4) * 4;
@@ -354,6 +415,16 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
             if (row < iend) G[(int64_t)(row - a.r0) * E + e0 + (lane & 15)] = acc[q];
         }
     }
+    if (!a.fuse) return;
+    // the stripe's last column slice adds the slices' partial rows and applies the normalisation backward
+    const int nstripe = gridDim.x;
+    if (last_arriver(a.arrive + 1 + dir * nstripe + blockIdx.x, (unsigned)a.zs)) {
+#pragma unroll 1
+        for (int r = wave; r < 16; r += 4)
+            if (i0 + r < iend) loss_finalize_row(a, dir, i0 - a.r0 + r, lane);
+    }
+    // ... and the call's last workgroup the scalars
+    if (last_arriver(a.arrive, gridDim.x * gridDim.y * gridDim.z)) loss_write_total(a);
 }
 
 // pass-A-only call of the row-block mode: the owned rows' statistics, slices added in order, for the caller's all-gather
@@ -365,41 +436,9 @@ __global__ void loss_stats_out_kernel(LossArgs a) {
     a.stats_out[i] = v;
 }
 
-// normalisation backward: x_hat = x / |x|  =>  dx = (g - x_hat (x_hat . g)) / |x| ; added to the tower-term gradient
-__global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);          // owned row (local index)
-    if (b >= a.Bl) return;
-    for (int tow = 0; tow < 2; ++tow) {
-        const float* xh = a.nrm[tow] + (int64_t)(a.r0 + b) * a.E;
-        float* g = a.dsh[tow] + (int64_t)b * a.E;
-        const int64_t zstride = (int64_t)a.Bl * a.E;
-        float dot = 0.f;
-        for (int c = lane * 4; c < a.E; c += 256) {
-            float4 y = *(const float4*)(g + c);
-            for (int zz = 1; zz < a.zs; ++zz) {                     // slice order: deterministic
-                const float4 p = *(const float4*)(g + zz * zstride + c);
-                y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
-            }
-            *(float4*)(g + c) = y;                                  // slice 0 now holds the complete row
-            const float4 x = *(const float4*)(xh + c);
-            dot += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-        }
-        dot = wave_sum(dot);
-        const float inv = a.inv[tow][b];
-        float* d = a.ds[tow] + (int64_t)b * a.E;
-        for (int c = lane * 4; c < a.E; c += 256) {
-            const float4 x = *(const float4*)(xh + c), y = *(const float4*)(g + c);
-            float4 o = *(const float4*)(d + c);
-            o.x += (y.x - x.x * dot) * inv; o.y += (y.y - x.y * dot) * inv;
-            o.z += (y.z - x.z * dot) * inv; o.w += (y.w - x.w * dot) * inv;
-            *(float4*)(d + c) = o;
-        }
-    }
-}
-
 // out[0] total ; [1..4] image l1,cos,kl,ce ; [5..8] text ; [9..12] cos_diff, hard_label, soft_label, logits_mse (raw)
-__global__ void loss_total_kernel(LossArgs a) {
+// (run by every thread of the call's last-arriving workgroup)
+__device__ void loss_write_total(const LossArgs& a) {
     __shared__ float tot[NSC];
     if (threadIdx.x < NSC) {
         float x = 0.f;
@@ -435,14 +474,28 @@ __global__ void loss_total_kernel(LossArgs a) {
     for (int i = 0; i < 16; ++i) a.out[i] = o[i];
 }
 
+// default path: the normalisation backward of every owned row (one wave each) as a launch of its own; the extra last workgroup writes
+// the 16 scalars (they depend on the earlier launches only, not on this one)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
+    if (blockIdx.x == gridDim.x - 1) { loss_write_total(a); return; }
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);          // owned row (local index)
+    if (b >= a.Bl) return;
+    loss_finalize_row(a, 0, b, lane);
+    loss_finalize_row(a, 1, b, lane);
+}
+__global__ __launch_bounds__(64) void loss_total_kernel(LossArgs a) { loss_write_total(a); }
+
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+// arrival counters behind the scalar accumulators: one for the call, one per (direction, 16-row stripe)
+inline size_t arrive_bytes(int64_t rows) { return align_up((size_t)(1 + 2 * ((rows + 15) / 16)) * sizeof(unsigned)); }
 
 }  // namespace
 
 extern "C" size_t dclip_distill_loss_workspace(int64_t B, int64_t E) {
     const size_t be = align_up((size_t)B * E * sizeof(float));
     const size_t zs = 8;                                     // upper bound of loss_slices() for any row block
-    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up((size_t)NREP * SCSTRIDE * 4);
+    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up((size_t)NREP * SCSTRIDE * 4) + arrive_bytes(B);
 }
 
 namespace {
@@ -484,15 +537,25 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
     for (int i = 0; i < 2; ++i) { a.dsh[i] = (float*)w; w += (size_t)a.zs * be; }
     a.inv[0] = (float*)w; a.inv[1] = a.inv[0] + rows; w += align_up((size_t)2 * B * 4);
     a.stats = (float*)w; w += align_up((size_t)a.zs * 6 * B * 4);
-    a.scal = (float*)w;
+    a.scal = (float*)w; w += align_up((size_t)NREP * SCSTRIDE * 4);
+    a.arrive = (unsigned*)w;
+    const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
+    a.final_in_rows = cross ? 0 : 1;
+    // DCLIP_LOSS_FUSE=1: three kernels (rows, stripe A, stripe B) with the follow-up work done by last-arriving workgroups.  Measured
+    // slower than the default four (rows, A, B, finalize + scalars) on the 8-XCD part: 0.176 against 0.136 ms per call at B = 512 — the
+    // agent-scope release / acquire fences of 256 workgroups write back and invalidate their XCD's L2
+    static const int fuse = [] { const char* e = getenv("DCLIP_LOSS_FUSE"); return e ? atoi(e) : 0; }();
+    a.fuse = fuse;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic HBM bytes: read 4*B*E*4 + write 2*rows*E*4 ; the logits contribute none
     TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 2.0 : 1.0) * (2.0 * (double)B + (double)rows) * E * 4.0, stream);
-    if (hipMemsetAsync(a.scal, 0, (size_t)NREP * SCSTRIDE * sizeof(float), st) != hipSuccess) {
+    // launches of a call: this fill (accumulators + arrival counters, adjacent), rows, and with cross-modal terms stripe A, stripe B
+    // and the normalisation backward, whose extra workgroup writes the 16 scalars (round 3: a fifth launch)
+    if (hipMemsetAsync(a.scal, 0, align_up((size_t)NREP * SCSTRIDE * sizeof(float)) + arrive_bytes(rows), st) != hipSuccess) {
         dclip_set_error("%s: memset failed", who);
         return DCLIP_ELAUNCH;
     }
-    const dim3 allrows((unsigned)((B + 3) / 4)), ownrows((unsigned)((rows + 3) / 4));
+    const dim3 allrows((unsigned)((B + 3) / 4));
     const int nv = (int)((E + 255) / 256);
     switch (nv) {
         case 1: hipLaunchKernelGGL((loss_rows_kernel<1>), allrows, dim3(256), 0, st, a); break;
@@ -500,7 +563,6 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
         case 3: hipLaunchKernelGGL((loss_rows_kernel<3>), allrows, dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((loss_rows_kernel<4>), allrows, dim3(256), 0, st, a); break;
     }
-    const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
     if (cross) {
         const dim3 grid((unsigned)((rows + 15) / 16), 2, (unsigned)a.zs);
         hipLaunchKernelGGL(loss_stripe_a_kernel, grid, dim3(256), 0, st, a);
@@ -511,9 +573,10 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
         const size_t lds = (size_t)16 * (((((B + 15) / 16) + a.zs - 1) / a.zs) * 16 + 4) * sizeof(float);
         DCLIP_REQUIRE(lds <= 160 * 1024, "%s: stripe does not fit LDS", who);
         hipLaunchKernelGGL(loss_stripe_b_kernel, grid, dim3(256), lds, st, a);
-        hipLaunchKernelGGL(loss_finalize_kernel, ownrows, dim3(256), 0, st, a);
+        if (!a.fuse) hipLaunchKernelGGL(loss_finalize_kernel, dim3((unsigned)((rows + 3) / 4) + 1), dim3(256), 0, st, a);
+    } else if (!a.fuse) {
+        hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a);
     }
-    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a);
     return dclip_check_launch(who);
 }
 
