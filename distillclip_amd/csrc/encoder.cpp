@@ -134,6 +134,7 @@ struct Work {
     bf16_t* hf;                            // [B, D]
     // temporaries
     float* x0;                             // teacher image pre-ln_pre tokens
+    bf16_t* delta;                         // [M, D] output of a block execution's second MLP linear while its residual add is pending
     float* G; bf16_t* Gb;                  // residual-stream gradient
     // gradients that are wgrad operands keep one slot per repeat: the R executions of a weight-shared block feed ONE
     // wgrad GEMM over R * M rows (half the launches and half the f32 atomic traffic at R = 2)
@@ -194,6 +195,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     w.meanf = b.take<float>(B); w.rstdf = b.take<float>(B);
     w.hf = b.take<bf16_t>(B * D);
     w.x0 = (!p.student && p.image) ? b.take<float>(M * D) : nullptr;
+    w.delta = b.take<bf16_t>(M * D);
     if (save) {
         w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
         w.gb_f2 = b.take<bf16_t>(p.R * M * D); w.gb_pr = b.take<bf16_t>(p.R * M * D);
@@ -231,6 +233,22 @@ inline bool mix_attn(const Plan& p, int64_t N) {
     static const int mode = [] { const char* e = getenv("DCLIP_ATTN_MIX"); return e ? atoi(e) : 1; }();
     return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_mix_supported(p.H, N, p.hd) != 0;
 }
+
+// The residual add behind the MLP (x = x + mlp(ln_2(x)): _common.py:125, weight_share_model.py:184) leaves the fc2 GEMM's epilogue,
+// where the f32 stream was read and re-written by 256 workgroups at once with the matrix pipe idle (25600 x 768 x 3072: 141 us
+// against 91 us with a bf16 store), and is done by the LayerNorm that opens the next block execution (dclip_layernorm_fwd_add:
+// +20 us for the extra 39 MB read and 79 MB written at streaming rate).  Same HBM bytes, ~30 us less per block execution in
+// isolation — and nothing in the four-stream step (gemm_nt -0.5 ms, ln_fwd +0.64 ms per step, throughput within noise: the other
+// towers' kernels already fill the time a residual epilogue spends waiting for HBM), while the linear's output gets rounded to
+// bf16 before the add (as the reference's fp16 autocast rounds it to fp16).  Hence OPT-IN: DCLIP_DEFER_RESIDUAL=1; the default
+// keeps the add in the GEMM epilogue.
+inline int defer_residual_mode() {
+    static const int mode = [] { const char* e = getenv("DCLIP_DEFER_RESIDUAL"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+inline bool defer_mlp_residual() { return defer_residual_mode() != 0; }
+// =2 (experiment): the attention projection's add as well, done by ln_2 of the same execution
+inline bool defer_attn_residual() { return defer_residual_mode() == 2; }
 
 // split count of the wgrad contraction: minimise  rounds(tiles*s / 512 resident workgroups) * work per workgroup
 //                                                   + atomic traffic (s * P*Q*4 bytes at ~1.3 TB/s, half hidden)
@@ -393,6 +411,7 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
     }
 
     // ---- blocks --------------------------------------------------------------------------------------------
+    const float* pending_x = nullptr;      // x_mid of the previous execution while its MLP residual add is pending (w.delta)
     for (int ei = 0; ei < nex; ++ei) {
         const int l = ei / p.R, r = ei % p.R;
         const auto& bw = p.bw[l];
@@ -410,7 +429,12 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
         }
         float* xin = w.X[ei];
         float* xout = w.X[ei + 1];
-        CK(dclip_layernorm_fwd(xin, D, nullptr, n1w, n1b, s.h1, D, 0, s.mean1, s.rstd1, M, D, 1e-5f, st));
+        if (pending_x) {   // the previous execution's MLP output is still to be added: xin = x_mid(previous) + delta, then ln_1
+            CK(dclip_layernorm_fwd_add(pending_x, D, w.delta, D, xin, D, n1w, n1b, s.h1, D, s.mean1, s.rstd1, M, D, 1e-5f, st));
+            pending_x = nullptr;
+        } else {
+            CK(dclip_layernorm_fwd(xin, D, nullptr, n1w, n1b, s.h1, D, 0, s.mean1, s.rstd1, M, D, 1e-5f, st));
+        }
         CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         if (!training && !wl) {
             // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
@@ -427,10 +451,22 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
                 CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, 0, st));
             }
         }
-        CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
-        CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
+        if (defer_attn_residual()) {
+            CK(gemm(s.ctx, D, W + bw.proj, D, w.delta, D, M, D, D, bp, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+            CK(dclip_layernorm_fwd_add(xin, D, w.delta, D, s.x_mid, D, n2w, n2b, s.h2, D, s.mean2, s.rstd2, M, D, 1e-5f, st));
+        } else {
+            CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
+            CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
+        }
         CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
-        CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
+        // every execution but the last hands its MLP output to the next execution's ln_1 (defer_mlp_residual); the last one, and any
+        // execution whose hidden state is exported, adds it in the GEMM epilogue so that X[ei + 1] exists when this loop ends
+        if (defer_mlp_residual() && ei + 1 < nex && !(rep_out && rep_out[ei])) {
+            CK(gemm(s.u, F, W + bw.fc2, F, w.delta, D, M, D, F, b2, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
+            pending_x = s.x_mid;
+        } else {
+            CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
+        }
         // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
         if (rep_out && rep_out[ei] &&
             hipMemcpyAsync(rep_out[ei], xout, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {

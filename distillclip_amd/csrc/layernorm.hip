@@ -9,11 +9,15 @@ namespace {
 
 constexpr int LN_MAXV = 4;   // float4 chunks per lane: D <= 64 * 4 * 4 = 1024
 
-template <int NV, bool OUT_F32>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int* __restrict__ ridx,
+// ADD: the row normalised is x[row] + delta[row] (delta bf16: the output of the linear that feeds the residual stream), and that sum
+// is also written to xsum[row] — the residual add of `x = x + mlp(ln_2(x))` done here instead of in the GEMM's epilogue (x and xsum
+// are not restrict-qualified: they are the same buffer in the inference towers)
+template <int NV, bool OUT_F32, bool ADD>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, int64_t ldx, const int* __restrict__ ridx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      void* __restrict__ y, int64_t ldy, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int D, float eps) {
+                                                     float* __restrict__ rstd, int M, int D, float eps,
+                                                     const bf16_t* __restrict__ delta, int64_t ldd, float* xsum, int64_t ldxs) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -25,6 +29,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         v[i] = c < D ? *(const float4*)(xr + c) : float4{0.f, 0.f, 0.f, 0.f};
+        if (ADD && c < D) {
+            const bf16x4 d = *(const bf16x4*)(delta + src * ldd + c);
+            v[i].x += bf2f(d[0]); v[i].y += bf2f(d[1]); v[i].z += bf2f(d[2]); v[i].w += bf2f(d[3]);
+            *(float4*)(xsum + src * ldxs + c) = v[i];
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mu = wave_sum(s) / D;
@@ -210,9 +219,27 @@ extern "C" int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* r
     hipStream_t st = (hipStream_t)stream;
     TraceScope tr(DCLIP_TRACE_LAYERNORM, 8.0 * (double)M * D, (double)M * D * (4.0 + (out_f32 ? 4.0 : 2.0)), stream);
     LN_DISPATCH(nv,
-        if (out_f32) hipLaunchKernelGGL((ln_fwd_kernel<NV, true>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps);
-        else hipLaunchKernelGGL((ln_fwd_kernel<NV, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps));
+        if (out_f32) hipLaunchKernelGGL((ln_fwd_kernel<NV, true, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps, nullptr, 0, nullptr, 0);
+        else hipLaunchKernelGGL((ln_fwd_kernel<NV, false, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps, nullptr, 0, nullptr, 0));
     return dclip_check_launch("dclip_layernorm_fwd");
+}
+
+extern "C" int dclip_layernorm_fwd_add(const float* x, int64_t ldx, const void* delta, int64_t ldd, float* xsum, int64_t ldxs,
+                                       const float* gamma, const float* beta, void* y, int64_t ldy, float* mean, float* rstd,
+                                       int64_t M, int64_t D, float eps, void* stream) {
+    DCLIP_REQUIRE(x && delta && xsum && gamma && beta && y, "dclip_layernorm_fwd_add: null operand");
+    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_fwd_add: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
+    DCLIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldd % 4 == 0 && ldxs % 4 == 0 && ((uintptr_t)delta % 8) == 0 && ((uintptr_t)xsum % 16) == 0,
+                  "dclip_layernorm_fwd_add: row strides must be multiples of 4, delta 8-byte and xsum 16-byte aligned");
+    const int nv = (int)((D + 255) / 256);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes: read x (4) + delta (2), write the sum (4) + the normalised bf16 rows (2)
+    TraceScope tr(DCLIP_TRACE_LAYERNORM, 9.0 * (double)M * D, (double)M * D * 12.0, stream);
+    LN_DISPATCH(nv,
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, false, true>), grid, dim3(256), 0, st, x, ldx, nullptr, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps,
+                           (const bf16_t*)delta, ldd, xsum, ldxs));
+    return dclip_check_launch("dclip_layernorm_fwd_add");
 }
 
 extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx,

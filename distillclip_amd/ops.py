@@ -86,6 +86,22 @@ def layernorm_fwd(x, gamma, beta, *, row_index=None, out_dtype=torch.bfloat16, e
     return y, mean, rstd
 
 
+def layernorm_fwd_add(x, delta, gamma, beta, *, xsum=None, eps=1e-5, save_stats=True):
+    """xsum = x + delta (bf16 delta: a linear's output; xsum may be x itself), y = LN(xsum) in bf16: the residual add of
+    `x = x + mlp(ln_2(x))` (reference _common.py:125, weight_share_model.py:184) done by the LayerNorm that reads the sum next"""
+    _chk(x, delta, gamma, beta, xsum)
+    assert x.dtype == torch.float32 and delta.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and delta.stride(1) == 1
+    M, D = x.shape
+    if xsum is None:
+        xsum = torch.empty_like(x)
+    y = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    lib().dclip_layernorm_fwd_add(_p(x), x.stride(0), _p(delta), delta.stride(0), _p(xsum), xsum.stride(0), _p(gamma), _p(beta),
+                                  _p(y), D, _p(mean), _p(rstd), M, D, eps, _stream())
+    return y, xsum, mean, rstd
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_acc, *, row_index=None, dx_bf16=None, dgamma=None, dbeta=None, colsum=None):
     _chk(dy, x, gamma, mean, rstd, dx_acc, dx_bf16, dgamma, dbeta)
     M, D = dy.shape

@@ -89,6 +89,13 @@ int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N,
 int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
                         void* y, int64_t ldy, int out_f32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                         void* stream);
+/* fwd_add: the residual add of `x = x + self.mlp(self.ln_2(x))` (reference: model/component/_common.py:123-125 ResidualAttentionBlock.forward,
+ *      weight_share_model.py:180-184 MiniBlock.forward) fused into the LayerNorm that reads the sum next:
+ *      xsum[r] = x[r] + delta[r] (delta bf16 [M, D] = the linear's output, bias included; xsum may be x itself), y[r] = LN(xsum[r]).
+ *      The linear's GEMM then stores bf16 instead of reading and re-writing the f32 stream in its epilogue. */
+int dclip_layernorm_fwd_add(const float* x, int64_t ldx, const void* delta, int64_t ldd, float* xsum, int64_t ldxs,
+                            const float* gamma, const float* beta, void* y, int64_t ldy, float* mean, float* rstd,
+                            int64_t M, int64_t D, float eps, void* stream);
 int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx, const int32_t* row_index,
                         const float* gamma, const float* mean, const float* rstd, float* dx_acc, int64_t lddx,
                         void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, float* colsum_acc, int64_t M, int64_t D,

@@ -7,19 +7,22 @@ with the fields of the reference's output dataclasses (model/component/output.py
 import contextlib
 import math
 import torch
+import os
 import torch.nn.functional as F
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Rounding-matched mode (test infrastructure for tight END-TO-END gradient parity).  The HIP path stores GEMM operands as
 # bf16; against the plain fp32 oracle that costs ~1e-2 per block execution on gradients, which hides a
 # backward error of a few per cent.  Inside `with bf16_matched():` this restatement rounds to bf16 at the SAME points —
-# forward: weights, LayerNorm outputs, qkv, probabilities, mixed probabilities, context, gelu output, picked final row,
-# im2row patches; backward: the gradient of every one of those tensors plus the residual-stream gradient where it enters a
+# forward: weights, LayerNorm outputs, qkv, probabilities, mixed probabilities, context, gelu output, (with the opt-in
+# DCLIP_DEFER_RESIDUAL=1) the MLP output of every block execution whose residual add is done by the next LayerNorm, picked final row, im2row patches; backward: the gradient of every one of those tensors plus the residual-stream gradient where it enters a
 # GEMM (fc2 / proj / head / embedding outputs), the pre-mix scores, and gelu'(z) saved as bf16 — while accumulation stays
 # fp32 on both sides.  What remains is accumulation order and rare rounding flips: ~1e-3.  The arithmetic between the
 # rounding points is unchanged, and tests/test_oracle_golden.py holds this mode to the pinned fp32 oracle within bf16 noise.
 # ---------------------------------------------------------------------------------------------------------------------
 _MATCHED = False
+# the HIP path's opt-in DCLIP_DEFER_RESIDUAL (MLP output handed to the next ln_1 as bf16) adds one rounding point to the matched mode
+_DEFER = os.environ.get('DCLIP_DEFER_RESIDUAL', '0') not in ('', '0')
 
 
 @contextlib.contextmanager
@@ -127,7 +130,12 @@ def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, n
         x = x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}')
         h = Q(_ln(x, sd, p + 'ln_2'))
         u = Q(quick_gelu(_lin(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'])))
-        x = x + _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'])
+        mlp = _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'])
+        # (matched mode under DCLIP_DEFER_RESIDUAL=1 only: the HIP path then hands the MLP output of every block but the last / an
+        #  exported one to the next ln_1 as bf16 — dclip_layernorm_fwd_add — where the reference's fp16 autocast rounds it to fp16)
+        if _DEFER and i + 1 < layers and not (need_rep and (need_layers is None or i in need_layers)):
+            mlp = Qf(mlp)
+        x = x + mlp
         if cap is not None:
             cap[f'tblock{i}.out'] = x
         if need_rep and (need_layers is None or i in need_layers):
@@ -210,7 +218,10 @@ def _student_blocks(x, sd, heads, repeats, use_transform, cap, need_rep=False):
             x = x + _mini_attention(h, sd, p + 'attn.', r, heads, use_transform, cap, tag)
             h = Q(_ln(x, sd, p + f'norm2.instances.{r}'))
             u = _gelu(_lin(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias']))         # timm Mlp, exact erf GELU
-            x = x + _lin(u, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], grad_operand=True)
+            mlp = _lin(u, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], grad_operand=True)
+            if _DEFER and not (i == n_blocks - 1 and r == repeats - 1) and not need_rep:       # (matched mode only, as in _teacher_blocks)
+                mlp = Qf(mlp)
+            x = x + mlp
             if cap is not None:
                 cap[tag + '.out'] = x
             if need_rep:

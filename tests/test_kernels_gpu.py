@@ -47,6 +47,26 @@ def test_layernorm_fwd_bwd(M, D):
     _close(db, br.grad, 2e-5, 'dbeta')
 
 
+@pytest.mark.parametrize('M,D', [(37, 512), (64, 768), (9, 1024), (5, 128)])
+def test_layernorm_fused_residual_add(M, D):
+    """dclip_layernorm_fwd_add: the MLP's residual add done by the next LayerNorm (reference _common.py:125 then :123 of the next block),
+    out of place and in place (the inference towers' residual stream is one buffer)"""
+    from distillclip_amd import ops
+    x = _randn((M, D), 1, 2.0) + 0.5
+    d = _randn((M, D), 6, 0.7).to(torch.bfloat16)
+    g, b = _randn((D,), 2, 0.1) + 1, _randn((D,), 3, 0.1)
+    want_sum = x + d.float()
+    ref = F.layer_norm(want_sum, (D,), g, b, 1e-5)
+    y, xs, mean, rstd = ops.layernorm_fwd_add(x, d, g, b)
+    assert torch.equal(xs, want_sum)                       # one fp32 add per element: exact
+    _close(y, ref, 5e-3, 'y bf16')
+    y2, m2, r2 = ops.layernorm_fwd(want_sum, g, b)
+    assert torch.equal(y, y2) and torch.equal(mean, m2) and torch.equal(rstd, r2)      # same arithmetic as the plain kernel on the sum
+    xi = x.clone()
+    y3, xs3, _, _ = ops.layernorm_fwd_add(xi, d, g, b, xsum=xi)
+    assert xs3.data_ptr() == xi.data_ptr() and torch.equal(xi, want_sum) and torch.equal(y3, y)
+
+
 def test_layernorm_row_index():
     from distillclip_amd import ops
     x = _randn((40, 128), 1)

@@ -219,7 +219,11 @@ def test_tiny_backward_vs_rounding_matched_oracle(tiny):
             g, r = dict(mod.named_parameters())[name].grad.detach().cpu(), sd[name].grad
             D = g.numel() // 3
             e = max(rel_l2(g[:D], r[:D].numpy()), rel_l2(g[2 * D:], r[2 * D:].numpy()))
-        if e > 2.5e-2:                    # measured <= 1.5e-2 (fp32 oracle: 8e-2 / 1.5e-1 in the test above)
+        # measured <= 1.5e-2 (fp32 oracle: 8e-2 / 1.5e-1 in the test above).  Under the opt-in DCLIP_DEFER_RESIDUAL=1 the 2 x 2 / 4 x 4
+        # head-mix matrices of the second repeat reach 2.6e-2: the MLP output of the execution in front of it enters the residual
+        # stream as bf16 (dclip_layernorm_fwd_add; rounding a value that already differs by 1e-3 turns that into ~sqrt(1e-3 * ulp))
+        deferred = os.environ.get('DCLIP_DEFER_RESIDUAL', '0') not in ('', '0')
+        if e > (3.5e-2 if deferred and '.attn.conv_' in n else 2.5e-2):
             bad[n] = e
     assert not bad, bad
 
