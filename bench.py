@@ -348,8 +348,8 @@ def dry_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=sorted(WORKLOADS), default='lclip',
                     help='lclip = BASELINE.json configs[3] (the headline metric); image / text / lclip336 = configs[1] / [2] / [4]')
     ap.add_argument('--batch', type=int, default=0, help='units per GPU (default: the configuration\'s own batch)')

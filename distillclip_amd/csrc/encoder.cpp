@@ -360,13 +360,16 @@ static int clear_backward_seeds(const Plan& p, const Work& w, int64_t M, void* s
     return DCLIP_OK;
 }
 
-extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
-                                     const void* wcache, void* workspace, size_t ws_bytes, int training,
-                                     float* last_representation, float* const* rep_out, float* emb_out, int64_t tokens_eff,
-                                     void* st) {
-    DCLIP_REQUIRE(e && input && params && wcache && workspace && last_representation, "dclip_encoder_forward: null argument");
+// ext_patches: the image tower's [B*N, K] bf16 patch rows made by the caller (dclip_im2row, cls_rows = 1) — two towers that
+// see the same images and cut them the same way share one conversion; null: this call converts `input` itself
+static int encoder_forward_impl(const dclip_encoder* e, const void* input, const bf16_t* ext_patches, int64_t B, const void* const* params,
+                                const void* wcache, void* workspace, size_t ws_bytes, int training,
+                                float* last_representation, float* const* rep_out, float* emb_out, int64_t tokens_eff,
+                                void* st) {
+    DCLIP_REQUIRE(e && (input || ext_patches) && params && wcache && workspace && last_representation, "dclip_encoder_forward: null argument");
     DCLIP_REQUIRE(B > 0, "dclip_encoder_forward: empty batch");
     const Plan& p = e->p;
+    DCLIP_REQUIRE(!ext_patches || (p.image && ((uintptr_t)ext_patches % 16) == 0), "dclip_encoder_forward_patches: image towers only, 16-byte aligned rows");
     DCLIP_REQUIRE(!training || p.student, "dclip_encoder_forward: the teacher tower is inference-only");
     // tokens_eff: causal text teacher only.  Positions after the longest caption's EOT cannot influence any EOT row (causal
     // attention; LN / MLP are per token), so the tower may run on the first tokens_eff positions with identical output.
@@ -383,13 +386,14 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
 
     // ---- embedding -----------------------------------------------------------------------------------------
     if (p.image) {
-        CK(dclip_im2row((const float*)input, w.patches, B, p.c.in_chans, p.c.resolution, p.c.patch, 1, st));
+        const bf16_t* patches = ext_patches ? ext_patches : w.patches;
+        if (!ext_patches) CK(dclip_im2row((const float*)input, w.patches, B, p.c.in_chans, p.c.resolution, p.c.patch, 1, st));
         if (p.student) {   // params: 0 conv w, 1 conv b, 2 cls_token, 3 pos_embed
             CK(dclip_token_table(PF(params, 3), PF(params, 2), PF(params, 1), w.tok_table, N, D, st));
-            CK(gemm(w.patches, p.K, W + p.w_embed, p.K, w.X[0], D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
+            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.X[0], D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
         } else {           // params: 0 conv1 w, 1 class_embedding, 2 positional_embedding, 3 ln_pre w, 4 ln_pre b
             CK(dclip_token_table(PF(params, 2), PF(params, 1), nullptr, w.tok_table, N, D, st));
-            CK(gemm(w.patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
+            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
             CK(dclip_layernorm_fwd(w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, 1, nullptr, nullptr, M, D, 1e-5f, st));
         }
     } else if (p.compressed) {   // params: 0 table [V,rank], 1 linear w [D,rank], 2 linear b, 3 pos
@@ -484,6 +488,23 @@ extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, 
     return DCLIP_OK;
 }
 
+extern "C" int dclip_encoder_forward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
+                                     const void* wcache, void* workspace, size_t ws_bytes, int training,
+                                     float* last_representation, float* const* rep_out, float* emb_out, int64_t tokens_eff,
+                                     void* st) {
+    DCLIP_REQUIRE(input, "dclip_encoder_forward: null argument");
+    return encoder_forward_impl(e, input, nullptr, B, params, wcache, workspace, ws_bytes, training, last_representation, rep_out, emb_out,
+                                tokens_eff, st);
+}
+
+extern "C" int dclip_encoder_forward_patches(const dclip_encoder* e, const void* patches, int64_t B, const void* const* params,
+                                             const void* wcache, void* workspace, size_t ws_bytes, int training,
+                                             float* last_representation, float* const* rep_out, float* emb_out, void* st) {
+    DCLIP_REQUIRE(patches, "dclip_encoder_forward_patches: null argument");
+    return encoder_forward_impl(e, nullptr, (const bf16_t*)patches, B, params, wcache, workspace, ws_bytes, training, last_representation,
+                                rep_out, emb_out, 0, st);
+}
+
 // All-token output of the final norm + projection (reference _common.py:210-215, text_encoder.py:69-72,
 // weight_share_model.py:363-366 / :503-506: `last_layer_output`, of which `last_representation` is one row per sample).  The
 // training path projects only the picked row; this call produces the whole [B*N, E] tensor on request from the residual
@@ -505,12 +526,13 @@ extern "C" int dclip_encoder_last_layer_output(const dclip_encoder* e, int64_t B
     return DCLIP_OK;
 }
 
-extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
-                                      void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
-                                      const float* d_last_representation, const float* const* d_rep, const float* d_emb,
-                                      dclip_bucket_cb on_bucket, void* cb_user, void* st) {
-    DCLIP_REQUIRE(e && input && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
+static int encoder_backward_impl(const dclip_encoder* e, const void* input, const bf16_t* ext_patches, int64_t B, const void* const* params,
+                                 void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                                 const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                                 dclip_bucket_cb on_bucket, void* cb_user, void* st) {
+    DCLIP_REQUIRE(e && (input || ext_patches) && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
     const Plan& p = e->p;
+    DCLIP_REQUIRE(!ext_patches || p.image, "dclip_encoder_backward_patches: image towers only");
     DCLIP_REQUIRE(p.student, "dclip_encoder_backward: only the student tower trains");
     Work w;
     layout(p, B, true, workspace, w);
@@ -596,7 +618,7 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     if (d_emb) CK(dclip_axpy_f32(w.G, d_emb, w.Gb, M * D, nullptr, D, st));
     if (hipMemsetAsync(w.tok_sum, 0, (size_t)N * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
     if (p.image) {           // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
-        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), w.tn_ws, w.tn_ws_bytes, st));
+        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, ext_patches ? ext_patches : w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), w.tn_ws, w.tn_ws_bytes, st));
         if (GR(1) || GR(2) || GR(3)) {
             CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));
             CK(dclip_token_table_bwd(w.tok_sum, GR(3), GR(2), GR(1), N, D, 1, st));
@@ -621,6 +643,24 @@ extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input,
     }
     if (on_bucket) on_bucket(cb_user, p.L + 1);          // embedding parameters: the last bucket
     return DCLIP_OK;
+}
+
+extern "C" int dclip_encoder_backward(const dclip_encoder* e, const void* input, int64_t B, const void* const* params,
+                                      void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                                      const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                                      dclip_bucket_cb on_bucket, void* cb_user, void* st) {
+    DCLIP_REQUIRE(input, "dclip_encoder_backward: null argument");
+    return encoder_backward_impl(e, input, nullptr, B, params, grads, wcache, workspace, ws_bytes, d_last_representation, d_rep, d_emb,
+                                 on_bucket, cb_user, st);
+}
+
+extern "C" int dclip_encoder_backward_patches(const dclip_encoder* e, const void* patches, int64_t B, const void* const* params,
+                                              void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                                              const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                                              dclip_bucket_cb on_bucket, void* cb_user, void* st) {
+    DCLIP_REQUIRE(patches, "dclip_encoder_backward_patches: null argument");
+    return encoder_backward_impl(e, nullptr, (const bf16_t*)patches, B, params, grads, wcache, workspace, ws_bytes, d_last_representation,
+                                 d_rep, d_emb, on_bucket, cb_user, st);
 }
 
 // Gradient buckets in the order the backward completes them (data-parallel exchange, SURVEY.md section 8e Collective 1):

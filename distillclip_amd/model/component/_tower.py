@@ -5,6 +5,7 @@ RCCL gradient exchange see a single contiguous tensor), the bf16 weight cache an
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -18,6 +19,56 @@ class EncoderCfg(ctypes.Structure):
 
 
 _BUCKET_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)      # include/dclip.h: dclip_bucket_cb
+
+
+_SHARE = threading.local()
+
+
+class shared_image_patches:
+    """Context: image towers that run inside it on the SAME image tensor with the same patch size take their patch rows from ONE
+    dclip_im2row conversion (made here, on the current stream) instead of converting the batch once each.  The reference feeds
+    teacher and student the same `image` (dual_distill_model.py:107-109) and both start with the same stride-p unfolding
+    (_common.py:196-198, weight_share_model.py:344).  A tower keeps the rows alive until its backward has used them (patch-embedding
+    wgrad).  No-op unless at least two of `towers` are image towers of equal patch size and channel count; DCLIP_SHARE_PATCHES=0
+    switches it off."""
+
+    def __init__(self, image, towers):
+        self.image, self.entry = image, None
+        tw = [t for t in towers if t is not None and t.cfg.modality == 0]
+        ok = (len(tw) >= 2 and isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.float32 and image.dim() == 4
+              and image.is_contiguous() and image.shape[2] == image.shape[3] and os.environ.get('DCLIP_SHARE_PATCHES', '1') != '0'
+              and len({(int(t.cfg.patch), int(t.cfg.in_chans)) for t in tw}) == 1 and image.shape[1] == tw[0].cfg.in_chans
+              and image.shape[-1] % 4 == 0 and tw[0].cfg.patch % 4 == 0)
+        if ok:
+            patch, chans, res, B = int(tw[0].cfg.patch), int(tw[0].cfg.in_chans), int(image.shape[-1]), int(image.shape[0])
+            grid = res // patch
+            rows = torch.empty((B * (grid * grid + 1), chans * patch * patch), dtype=torch.bfloat16, device=image.device)
+            lib().dclip_im2row(image.data_ptr(), rows.data_ptr(), B, chans, res, patch, 1, torch.cuda.current_stream().cuda_stream)
+            self.entry = dict(key=(image.data_ptr(), tuple(image.shape), image._version), patch=patch, chans=chans, rows=rows,
+                              stream=torch.cuda.current_stream())
+
+    def __enter__(self):
+        self.prev = getattr(_SHARE, 'entry', None)
+        _SHARE.entry = self.entry
+        return self
+
+    def __exit__(self, *exc):
+        _SHARE.entry = self.prev
+        return False
+
+
+def _shared_rows_for(x, cfg):
+    """the active share's patch rows if `x` is the tensor they were cut from and this tower cuts the same way, else None"""
+    e = getattr(_SHARE, 'entry', None)
+    if e is None or cfg.modality != 0 or e['key'] != (x.data_ptr(), tuple(x.shape), x._version):
+        return None
+    if int(cfg.patch) != e['patch'] or int(cfg.in_chans) != e['chans']:
+        return None
+    rows = e['rows']
+    cur = torch.cuda.current_stream()
+    if cur != e['stream']:
+        rows.record_stream(cur)                # cut on the share's stream (the tower streams wait for it), read on this one
+    return rows
 
 
 def _ptr_array(tensors):
@@ -260,10 +311,18 @@ class HipTower:
             reps = [slots[i] for i in want]
             rep_arr = _ptr_array(slots)
         emb = torch.empty((B, N, D), dtype=torch.float32, device=x.device) if need_emb else None
-        lib().dclip_encoder_forward(self._handle, x.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
-                                    self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
-                                    out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(), int(tokens_eff),
-                                    torch.cuda.current_stream().cuda_stream)
+        rows = _shared_rows_for(x, self.cfg) if not tokens_eff else None
+        self._patch_rows = rows if training else None      # (kept until the backward: operand of the patch-embedding wgrad)
+        if rows is not None:
+            lib().dclip_encoder_forward_patches(self._handle, rows.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
+                                                self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
+                                                out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+        else:
+            lib().dclip_encoder_forward(self._handle, x.data_ptr(), B, _ptr_array(ps), self.wcache.data_ptr(),
+                                        self.workspace.data_ptr(), self.workspace.numel(), 1 if training else 0,
+                                        out.data_ptr(), rep_arr, None if emb is None else emb.data_ptr(), int(tokens_eff),
+                                        torch.cuda.current_stream().cuda_stream)
         self._saved_batch = B if training else None
         self._last_fwd = (B, bool(training), int(tokens_eff))
         return out, x, reps, emb
@@ -326,15 +385,20 @@ class HipTower:
                     failed.append(exc)
             cb = _BUCKET_CB(_ready)
             self.dp_released = 0
-        lib().dclip_encoder_backward(self._handle, x.data_ptr(), B, _ptr_array(ps), _ptr_array(gs), self.wcache.data_ptr(),
-                                     self.workspace.data_ptr(), self.workspace.numel(), d_out.data_ptr(),
-                                     _ptr_array(keep) if any(g is not None for g in keep) else None,
-                                     None if d_emb is None else d_emb.data_ptr(),
-                                     ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None,
-                                     torch.cuda.current_stream().cuda_stream)
+        rows = getattr(self, '_patch_rows', None)
+        if rows is not None:
+            rows.record_stream(torch.cuda.current_stream())
+        call = lib().dclip_encoder_backward if rows is None else lib().dclip_encoder_backward_patches
+        call(self._handle, x.data_ptr() if rows is None else rows.data_ptr(), B, _ptr_array(ps), _ptr_array(gs), self.wcache.data_ptr(),
+             self.workspace.data_ptr(), self.workspace.numel(), d_out.data_ptr(),
+             _ptr_array(keep) if any(g is not None for g in keep) else None,
+             None if d_emb is None else d_emb.data_ptr(),
+             ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None,
+             torch.cuda.current_stream().cuda_stream)
         if failed:
             raise failed[0]
         self._saved_batch = None
+        self._patch_rows = None
         # gradient exchange may start as soon as THIS tower's backward is done (GradSync waits on this event, not on the
         # whole backward pass): the image tower's all-reduce overlaps the (longer) text tower backward
         if self.bwd_done is None:

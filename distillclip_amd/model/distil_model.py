@@ -13,6 +13,7 @@ from torch import nn
 from ._loss import LossCalculator
 from .utils import teacher_load
 from .component.weight_share_model import RepeatVisionTransformer
+from .component._tower import shared_image_patches
 from ..optim import FusedAdamW, EpochCosineSchedule
 from ..parallel import GradSync
 from ..metrics import retrieval_metrics, gather_rows
@@ -51,9 +52,11 @@ class DistillModel(nn.Module):
 
     def forward(self, inputs):
         # reference :81-89
-        student_outs = self.student(inputs, self.need_return_para)
-        with torch.no_grad():
-            teacher_outs = self.teacher(inputs, self.need_return_para)
+        # (image.yaml: teacher and student unfold the same images — one im2row for both when they cut them the same way; no-op for text)
+        with shared_image_patches(inputs, [getattr(self.student, '_tower', None), getattr(self.teacher, '_tower', None)]):
+            student_outs = self.student(inputs, self.need_return_para)
+            with torch.no_grad():
+                teacher_outs = self.teacher(inputs, self.need_return_para)
         if self.hparams.norm:
             # reference :86-88 (in place there; same values here, autograd-safe)
             for o in (student_outs, teacher_outs):

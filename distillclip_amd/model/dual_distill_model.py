@@ -16,6 +16,7 @@ from .utils import teacher_load
 from .component.clip_model import CLIPModel
 from .component.output import CLIPOutput
 from .component.weight_share_model import RepeatVisionTransformer
+from .component._tower import shared_image_patches
 from .distil_model import _HParams
 from ..optim import FusedAdamW, EpochCosineSchedule
 from ..parallel import GradSync
@@ -99,9 +100,7 @@ class DualDistillModel(nn.Module):
             events.append(ev)
         return CLIPOutput(visual_output=outs[0], text_output=outs[1]), events
 
-    def forward(self, inputs, teacher=None) -> Tuple[CLIPOutput, CLIPOutput]:
-        # reference :106-112.  The batch is (image, text) while CLIPModel.forward takes (text, image).
-        image, text = inputs
+    def _forward_towers(self, image, text, teacher):
         if not (self.multi_stream and image.is_cuda):
             student_outs = self.student(text, image, self.need_return_para)
             if teacher is not None:
@@ -144,6 +143,17 @@ class DualDistillModel(nn.Module):
                         t_.record_stream(main)
             teacher_outs = CLIPOutput(visual_output=outs[0], text_output=outs[1])
             student_outs = CLIPOutput(visual_output=outs[2], text_output=outs[3])
+        return student_outs, teacher_outs
+
+    def forward(self, inputs, teacher=None) -> Tuple[CLIPOutput, CLIPOutput]:
+        # reference :106-112.  The batch is (image, text) while CLIPModel.forward takes (text, image).
+        image, text = inputs
+        # teacher and student image towers unfold the same images: one im2row for both when they cut them the same way
+        towers = [getattr(self.student.image_encoder, '_tower', None)]
+        if teacher is None:
+            towers.append(getattr(self.teacher.image_encoder, '_tower', None))
+        with shared_image_patches(image, towers):
+            student_outs, teacher_outs = self._forward_towers(image, text, teacher)
         if self.hparams.norm:
             # reference :110-111 + norm_last_representation :278-284 (in place there; same values here, autograd-safe)
             for outs in (student_outs, teacher_outs):

@@ -5,8 +5,10 @@
  * The boundary this library replaces is therefore the implicit ATen kernel sequence behind the reference's
  * nn.Module calls.  Each entry point cites the reference call site (file:line under the reference root) whose
  * arithmetic it implements.  All pointers are raw device pointers; `stream` is a hipStream_t passed as void*.
- * No allocation and no synchronisation inside any entry point, and no global mutable state on the compute path: the only
- * process-global state is the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback
+ * No synchronisation inside any entry point and no allocation, with one exception: the persistent launches of dclip_gemm_nt draw
+ * their tiles from eight 4-byte ticket counters per stream (1 KiB, hipMalloc'ed and zeroed on that stream the first time a stream
+ * issues such a launch, kept for the life of the process; every launch leaves them at zero).  No other global mutable state on the
+ * compute path: the remaining process-global state is the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback
  * counter) and the tuning knobs read from DCLIP_* environment variables, which are latched once on first use and constant
  * afterwards.  Every function returns
  * 0 on success, DCLIP_EINVAL (-1) for a bad argument, DCLIP_ELAUNCH (-2) for a HIP launch failure, and
@@ -358,6 +360,13 @@ int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, v
 int dclip_encoder_forward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                           const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
                           float* const* rep_out, float* emb_out, int64_t tokens_eff, void* stream);
+/* The same forward on patch rows the caller has already cut: `patches` = bf16 [B*N, C*patch*patch] from dclip_im2row(..., cls_rows = 1).
+ * Teacher and student see the same image batch (reference dual_distill_model.py:107-109, distil_model.py forward) and, when their
+ * patch size and resolution agree, the same conv1 / PatchEmbed unfolding (_common.py:196-198, weight_share_model.py:344): one
+ * conversion then serves both towers.  Image towers only; the matching backward is dclip_encoder_backward_patches. */
+int dclip_encoder_forward_patches(const dclip_encoder* enc, const void* patches, int64_t B, const void* const* params,
+                                  const void* wcache, void* workspace, size_t ws_bytes, int training, float* last_representation,
+                                  float* const* rep_out, float* emb_out, void* stream);
 /* last_layer_output (reference output.py:16-35; _common.py:210-215, text_encoder.py:69-72, weight_share_model.py:363-366,
  * :503-506): final norm + projection of EVERY token, f32 [B*N, E], computed on request from the residual stream the most
  * recent dclip_encoder_forward(enc, ..., B, training) left in `workspace` (tokens_eff must have been 0).  scratch: bf16
@@ -374,6 +383,11 @@ int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t 
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
                            const float* d_last_representation, const float* const* d_rep, const float* d_emb,
                            dclip_bucket_cb on_bucket, void* cb_user, void* stream);
+/* backward of a forward that ran on caller-made patch rows (they are the patch-embedding wgrad's operand) */
+int dclip_encoder_backward_patches(const dclip_encoder* enc, const void* patches, int64_t B, const void* const* params,
+                                   void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,
+                                   const float* d_last_representation, const float* const* d_rep, const float* d_emb,
+                                   dclip_bucket_cb on_bucket, void* cb_user, void* stream);
 /* gradient buckets in completion order: 0 = final norm + head, 1..L = blocks L-1..0, L+1 = embedding parameters; each is the
  * range [first_param, end_param) of the canonical parameter order above. */
 int32_t dclip_encoder_num_grad_buckets(const dclip_encoder* enc);

@@ -148,6 +148,41 @@ def test_tiny_dual_training_step_vs_reference_golden(tiny, case):
     _grad_check(s_txt, tiny, f'{case}.s_txt.grad.', L1_TOL, 2 * L1_TOL)
 
 
+def test_shared_image_patches_between_teacher_and_student(tiny):
+    """teacher and student image towers take their patch rows from ONE im2row when they cut the same images the same way
+    (dclip_encoder_forward_patches / _backward_patches; reference dual_distill_model.py:107-109: both see `image`): embeddings and every
+    student gradient — the patch-embedding wgrad reads those rows — equal the separately converted run (embeddings bit for bit)"""
+    from distillclip_amd.model.component import _tower
+    image = torch.from_numpy(tiny['image']).cuda()
+
+    def run(share):
+        s_img, _, t_img, _ = _tiny_modules()
+        towers = [s_img._tower, t_img._tower] if share else []
+        with _tower.shared_image_patches(image, towers) as sh:
+            assert (sh.entry is not None) == share
+            from distillclip_amd.model.component.output import ControlOutput
+            co = ControlOutput()
+            so = s_img(image, co)
+            with torch.no_grad():
+                to = t_img(image, co)
+            used = (s_img._tower._patch_rows is not None)
+        assert used == share
+        (so.last_representation * to.last_representation).sum().backward()
+        assert s_img._tower._patch_rows is None               # released by the backward
+        return so.last_representation.detach().clone(), to.last_representation.clone(), {n: p.grad.clone() for n, p in s_img.named_parameters()}
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for n in a[2]:      # (same operands; LayerNorm / bias / small-wgrad sums are f32 atomics: equal up to summation order)
+        assert rel_l2(a[2][n], b[2][n].cpu().numpy()) < 1e-5, n
+    # a different tensor (same values) is not the tensor the rows were cut from: the tower converts it itself
+    s_img, _, _, _ = _tiny_modules()
+    with _tower.shared_image_patches(image, [s_img._tower, s_img._tower]):
+        from distillclip_amd.model.component.output import ControlOutput
+        s_img(image.clone(), ControlOutput())
+        assert s_img._tower._patch_rows is None
+
+
 def test_tiny_backward_smooth_loss_vs_oracle(tiny):
     """Backward accuracy with a smooth objective (out_cos + out_kl): isolates the kernels' own error from the
     sign / relu discontinuities of out_l1 and cos_diff."""
