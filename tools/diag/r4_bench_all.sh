@@ -4,7 +4,7 @@ set -o pipefail
 mkdir -p gpurun_out
 for c in lclip image text lclip336; do
   sfx=$([ $c = lclip ] && echo "" || echo "_$c")
-  timeout -k 10 400 python bench.py --config $c --steps 20 --warmup 5 2> gpurun_out/r04_bench$sfx.err | tail -1 > gpurun_out/r04_bench$sfx.json || { tail -5 gpurun_out/r04_bench$sfx.err; exit 1; }
+  timeout -k 10 400 python bench.py --config $c --steps 50 --warmup 10 2> gpurun_out/r04_bench$sfx.err | tail -1 > gpurun_out/r04_bench$sfx.json || { tail -5 gpurun_out/r04_bench$sfx.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open('gpurun_out/r04_bench$sfx.json').read())
