@@ -299,7 +299,11 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+#ifdef DCLIP_NT256_NO_PERSIST     // A/B builds only (tools/diag/ab_libs.sh): the tile loop compiled out of every variant
+constexpr bool nt256_persistent(int, bool) { return false; }
+#else
 constexpr bool nt256_persistent(int act, bool out_f32) { return !out_f32 && act != 3 && act != 4; }
+#endif
 
 // ticket counters of the persistent launches: 8 (one per XCD chunk, 128 B apart) per stream — launches of one stream run one after
 // another and every launch leaves its counters at zero, launches of different streams overlap.  Zeroed once, on the stream itself.
@@ -315,7 +319,9 @@ unsigned* nt256_tile_counters(hipStream_t st) {
     return c;
 }
 
-template <int ACT, bool OUT_F32, int MI>
+// WALK: the persistent variant (a tile loop around the body).  A separate instantiation, not a run-time mode: the loop structure alone
+// costs the kernel 1.5 % in the step's single-stream probe even when every workgroup owns one tile.
+template <int ACT, bool OUT_F32, int MI, bool WALK = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RH = MI / 2;                      // row tiles per phase
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // epilogue, and the f32 / DGELU / MULAUX epilogues have neither the scalar nor the vector registers for that (77 spilled SGPRs and
     // 90-255 spilled VGPRs when tried) — their launches in the step are single-round anyway (N = 512 / 768) or dominated by an
     // HBM-bound epilogue.
-    constexpr bool PERSIST = nt256_persistent(ACT, OUT_F32);
+    constexpr bool PERSIST = WALK && nt256_persistent(ACT, OUT_F32);
     const int nwg = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK;
     const int nload = 4 * nk;
@@ -1263,13 +1269,16 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
             tm = (p.M + mi * 32 - 1) / (mi * 32);
         }
         p.tiles_m = tm; p.tiles_n = tn;
-        // persistent launch: at most one workgroup per CU, each walking tiles b, b + grid, ... with the next tile's first operands
-        // requested under the current epilogue (DCLIP_GEMM_PERSIST=0: one workgroup per tile, =N: N workgroups, rounded to 8)
-        static const int persist = [] { const char* e = getenv("DCLIP_GEMM_PERSIST"); const int v = e ? atoi(e) : 1; return v == 1 ? 256 : (v & ~7); }();
+        // persistent launch (opt-in, DCLIP_GEMM_PERSIST=1: 256 workgroups, =N: N rounded down to a multiple of 8): at most one workgroup
+        // per CU, each drawing tiles from its XCD's ticket counter, the next tile's first operands requested under the current epilogue.
+        // Default 0: worth 1-4 % per shape in isolated loops and nothing on the step, while the tile loop costs the kernel 1.5 % in the
+        // step's single-stream probe
+        static const int persist = [] { const char* e = getenv("DCLIP_GEMM_PERSIST"); const int v = e ? atoi(e) : 0; return v == 1 ? 256 : (v & ~7); }();
         const int ntiles = p.tiles_m * p.tiles_n;
         const int grid256 = persist > 0 && ntiles > persist && nt256_persistent(ACT, out_f32) ? persist : ntiles;
         static const int tickets = [] { const char* e = getenv("DCLIP_GEMM_TICKETS"); return e ? atoi(e) : 1; }();
-        p.tile_ctr = grid256 < ntiles && tickets ? nt256_tile_counters(st) : nullptr;
+        const bool walk = grid256 < ntiles;                 // (implies a bf16 store and a persistent-capable epilogue)
+        p.tile_ctr = walk && tickets ? nt256_tile_counters(st) : nullptr;
         // raster group width: minimise the modelled operand bytes from beyond L2 —  A once per group, B once per XCD while a
         // group's B panels (256 x K bf16 each) fit ~2.5 MB of the XCD's 4 MB L2, else once per round of 32 tiles per XCD
         {
@@ -1288,17 +1297,20 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
         if (mi == 10) {
             const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2) + 16;
             if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
+            else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10, true>), dim3(grid256), dim3(512), lds320, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         if (mi == 6) {
             const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2) + 16;
             if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 6>), dim3(grid256), dim3(512), lds192, st, p);
+            else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6, true>), dim3(grid256), dim3(512), lds192, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6>), dim3(grid256), dim3(512), lds192, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         const size_t lds256 = 8 * HT + 16;
         if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 8>), dim3(grid256), dim3(512), lds256, st, p);
+        else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8, true>), dim3(grid256), dim3(512), lds256, st, p); }
         else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8>), dim3(grid256), dim3(512), lds256, st, p);
         if (!has_rest) return dclip_check_launch("dclip_gemm_nt");
         p = rest;

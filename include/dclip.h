@@ -5,7 +5,7 @@
  * The boundary this library replaces is therefore the implicit ATen kernel sequence behind the reference's
  * nn.Module calls.  Each entry point cites the reference call site (file:line under the reference root) whose
  * arithmetic it implements.  All pointers are raw device pointers; `stream` is a hipStream_t passed as void*.
- * No synchronisation inside any entry point and no allocation, with one exception: the persistent launches of dclip_gemm_nt draw
+ * No synchronisation inside any entry point and no allocation, with one exception: the opt-in persistent launches of dclip_gemm_nt (DCLIP_GEMM_PERSIST) draw
  * their tiles from eight 4-byte ticket counters per stream (1 KiB, hipMalloc'ed and zeroed on that stream the first time a stream
  * issues such a launch, kept for the life of the process; every launch leaves them at zero).  No other global mutable state on the
  * compute path: the remaining process-global state is the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback

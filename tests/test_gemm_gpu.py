@@ -319,3 +319,20 @@ def test_random_shapes_gemm_attention_products_wgrad_layernorm():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'diag', 'kernel_fuzz.py'), '25', '41'], capture_output=True, text=True,
                        timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_persistent_tile_walk_variants_match_the_same_references():
+    """The persistent instantiations of the 256- / 320-row kernel (tile loop, per-XCD ticket counters, next tile's operands requested
+    under the current epilogue; opt-in DCLIP_GEMM_PERSIST) are compiled into the shipped library: the GEMM tests
+    of this file are re-run in ONE child process with 8 workgroups per launch, so that every launch of more than 8 tiles walks many tiles
+    per workgroup (the knob is read once per process; the parent keeps no GPU work in flight meanwhile)."""
+    import os
+    import subprocess
+    import sys
+    torch.cuda.synchronize()
+    env = dict(os.environ, DCLIP_GEMM_PERSIST='8')
+    sel = 'gemm_nt and not persistent_tile_walk'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', sel, '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-2000:]
