@@ -1,5 +1,7 @@
 #!/bin/bash
-# lib_a = HEAD, lib_b = HEAD compiled with -DDCLIP_NT256_NO_PERSIST (the tile loop compiled out of every nt256 variant: the round-3 kernel structure)
+# lib_a = the tree with the tile loop compiled into the plain bf16 nt256 variants (persistent launches on by default), lib_b = the same tree with the
+# loop compiled out of every variant (a temporary -D switch; since then the loop lives in separate WALK = true instantiations).
+# Both libraries were built by hand into tools/diag/bin/ (not tracked); kept as the record of how the 1.5 % was measured.
 set -o pipefail
 mkdir -p gpurun_out
 cp distillclip_amd/libdistillclip_hip.so /tmp/lib_ship.so
