@@ -329,8 +329,10 @@ def test_persistent_tile_walk_variants_match_the_same_references():
     import os
     import subprocess
     import sys
+    if os.environ.get('DCLIP_TEST_CHILD'):
+        pytest.skip('already inside a child test process')
     torch.cuda.synchronize()
-    env = dict(os.environ, DCLIP_GEMM_PERSIST='8')
+    env = dict(os.environ, DCLIP_GEMM_PERSIST='8', DCLIP_TEST_CHILD='1')
     sel = 'gemm_nt and not persistent_tile_walk'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', sel, '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
