@@ -205,3 +205,21 @@ def test_persistent_gemm_ticket_walk_model_covers_every_tile_once():
             for tickets in (0, 1):
                 for seed in range(3):
                     launch(ntiles, min(grid, ntiles), tickets, seed)
+
+
+def test_shared_image_patches_is_a_no_op_without_two_matching_image_towers():
+    """shared_image_patches (one im2row for teacher + student) only engages for CUDA f32 images and at least two image towers that cut them the
+    same way; everything else — CPU tensors, one tower, text towers, different patch sizes, DCLIP_SHARE_PATCHES=0 — leaves every tower to its
+    own conversion (and must not touch the library: this runs without a GPU)."""
+    import types
+    import torch
+    from distillclip_amd.model.component import _tower
+
+    def tw(modality=0, patch=32, chans=3):
+        return types.SimpleNamespace(cfg=types.SimpleNamespace(modality=modality, patch=patch, in_chans=chans))
+    img = torch.zeros(2, 3, 64, 64)
+    for towers in ([tw(), tw()], [tw()], [tw(), tw(modality=1)], [tw(), tw(patch=16)], [None, tw()], []):
+        with _tower.shared_image_patches(img, towers) as sh:            # CPU image: never engages
+            assert sh.entry is None
+            assert _tower._shared_rows_for(img, tw().cfg) is None
+    assert getattr(_tower._SHARE, 'entry', None) is None
