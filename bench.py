@@ -559,7 +559,8 @@ def main():
             'config': {'workload': wl['desc'], 'name': args.config,
                        'global_batch': B * world, 'batch_per_gpu': B, 'parallelism': f'dp{world}', 'gradient_exchange': dp,
                        'negatives': 'global (all-gather over RCCL)' if args.global_negatives else 'local (reference training_step semantics)',
-                       'optimizer_in_step': True, 'teacher_text_tokens_processed': tt_tokens},
+                       'optimizer_in_step': True, 'teacher_text_tokens_processed': tt_tokens,
+                       'teacher_residual': 'fp16', 'saved_gelu_derivative': 'u8 fixed point', 'clock_probe': not args.no_clock_probe},
             f'step_gflop_per_{wl["unit"][:-1]}': wl['gflop'],
             'mfma_roofline_frac_whole_step': round(value / world * wl['gflop'] * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             'final_loss': round(final_loss, 6),

@@ -724,226 +724,6 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_mix_kernel(SoftmaxFwd p)
 
 // backward of the stage above.  dP = Ww^T dR ; dA = P o (dP - sum_j P dP) ; dS = Wl^T dA
 // dWw[g,h] += sum dR_g P_h ; dWl[g,h] += sum dA_g S_h     (32x32x16 MFMA over the key axis, per-wave accumulators)
-// ---------------------------------------------------------------------------------------------------------
-// Fused student attention forward: one workgroup per (sample, tile of RT query rows) runs
-//   A  S_h = scale * Q_h K_h^T for every head (MFMA, operands straight from the qkv rows in L2) -> LDS [H][RT][COLS] f32
-//   B  per query row: A = conv_l(S) (split-bf16 MFMA) -> softmax -> P -> R = conv_w(P), exactly the arithmetic of
-//      attn_softmax_fwd_mix_kernel; S (as bf16: the backward converts it anyway), P and R go to HBM for the backward,
-//      R also stays in LDS (over the row's f32 scores)
-//   C  ctx_h = R_h V_h per head (MFMA, V_h staged k-major in the wave's private tiles, transposed accumulators -> 8-byte stores)
-// The scores are written once (6 B / element) and never read back in the forward: attn_nt + softmax + attn_nn move 14 B / element.
-//   reference: weight_share_model.py:88-140 (MiniAttention.forward)
-// ---------------------------------------------------------------------------------------------------------
-struct StudentAttn {
-    const bf16_t* qkv; int64_t ld;      // [B*N, 3D], q | k | v
-    const float* Wl; const float* Ww;   // [H, H]
-    bf16_t* S; bf16_t* P; bf16_t* R;    // [B, H, N, Np] saved for the backward (S pre-mix scores as bf16)
-    bf16_t* ctx; int64_t ldc;           // [B*N, D]
-    int B, N, Np, D;
-    float scale;
-};
-
-template <int H, int NS, int HD>
-__global__ __launch_bounds__(256) void attn_student_fwd_kernel(StudentAttn p) {
-    constexpr int COLS = 64 * NS, ROWB = COLS * 2 + 16, NCT = COLS / 32, TILE = 32 * ROWB;
-    constexpr int RT = NS == 1 ? 16 : 8;                 // query rows per workgroup (LDS budget)
-    constexpr int KS = HD / 32, DT = HD / 16;
-    constexpr int VROWB = HD * 2 + 16;
-    static_assert(COLS * VROWB <= 3 * TILE, "V tile must fit the wave's private tiles");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Sall = (float*)smem;                          // [H][RT][COLS]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* tH = smem + (size_t)H * RT * COLS * 4 + wave * 3 * TILE;
-    char* tL = tH + TILE;
-    char* tP = tL + TILE;
-    const int ntile = (p.N + RT - 1) / RT;
-    const int b = blockIdx.x / ntile, i0 = (blockIdx.x % ntile) * RT;
-    const int g = lane >> 4, fr = lane & 15, fk = g * 8;
-    const bf16_t* qb = p.qkv + (int64_t)b * p.N * p.ld;
-
-    // ---- A: scores ------------------------------------------------------------------------------------------
-    for (int h = wave; h < H; h += 4) {
-        bf16x8 qf[KS];
-        const int qi = min(i0 + fr, p.N - 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qb + (int64_t)qi * p.ld + h * HD + ks * 32 + fk);
-#pragma unroll
-        for (int ct = 0; ct < COLS / 16; ++ct) {
-            if (ct * 16 >= p.Np) continue;
-            const int kj = min(ct * 16 + fr, p.N - 1);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(qb + (int64_t)kj * p.ld + p.D + h * HD + ks * 32 + fk);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * g + r < RT) Sall[((size_t)h * RT + 4 * g + r) * COLS + ct * 16 + fr] = ct * 16 + fr < p.N ? acc[r] * p.scale : 0.f;
-        }
-    }
-    // wave-private tiles: zero once (pad heads / pad keys stay zero) ; mix matrices as split-bf16 A operands
-    for (int idx = lane; idx < 3 * TILE / 16; idx += 64) ((u32x4*)tH)[idx] = u32x4{0u, 0u, 0u, 0u};
-    const int hh = lane >> 5, c = lane & 31;
-    bf16x8 aLh[2], aLl[2], aWh[2], aWl2[2], ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int h = 16 * s + 8 * hh + e;                                   // A[g = c][k = h]
-            const float wl = (h < H && c < H) ? p.Wl[c * H + h] : 0.f;
-            const bf16_t hi = f2bf(wl);
-            aLh[s][e] = hi;
-            aLl[s][e] = f2bf(wl - bf2f(hi));
-            const float ww = (h < H && c < H) ? p.Ww[c * H + h] : 0.f;
-            const bf16_t whi = f2bf(ww);
-            aWh[s][e] = whi;
-            aWl2[s][e] = f2bf(ww - bf2f(whi));
-        }
-    __syncthreads();
-
-    // ---- B: mix -> softmax -> mix, one query row per wave at a time ---------------------------------------------
-    const int64_t hs = (int64_t)p.N * p.Np;
-    const int nchunk = p.Np >> 3, total = H * nchunk;
-    for (int q = wave; q < RT; q += 4) {
-        const int i = i0 + q;
-        if (i >= p.N) break;
-        const int64_t base = ((int64_t)b * H * p.N + i) * p.Np;
-        __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < total; idx += 64) {
-            const int h = idx / nchunk, ck = idx - h * nchunk;
-            const float* sp = Sall + ((size_t)h * RT + q) * COLS + ck * 8;
-            const float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4);
-            const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { hi[e] = f2bf(v[e]); lo[e] = f2bf(v[e] - bf2f(hi[e])); }
-            *(bf16x8*)(tH + h * ROWB + ck * 16) = hi;
-            *(bf16x8*)(tL + h * ROWB + ck * 16) = lo;
-            if (p.S) *(bf16x8*)(p.S + base + h * hs + ck * 8) = hi;          // raw scores for dW_l (bf16 is what the backward uses)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        f32x16 am[NCT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            am[ct] = f32x16{0};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 bh = tr_frag32<ROWB>(tH, 16 * s, 32 * ct, lane), bl = tr_frag32<ROWB>(tL, 16 * s, 32 * ct, lane);
-                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLh[s], bh, am[ct], 0, 0, 0);
-                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLh[s], bl, am[ct], 0, 0, 0);
-                am[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aLl[s], bh, am[ct], 0, 0, 0);
-            }
-            const bool jok = 32 * ct + c < p.N;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gg = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (jok && gg < H) m = fmaxf(m, am[ct][r]);
-            }
-        }
-        m = wave_max(m);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const bool jok = 32 * ct + c < p.N;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gg = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float e = (jok && gg < H) ? __expf(am[ct][r] - m) : 0.f;
-                am[ct][r] = e;
-                *(bf16_t*)(tP + gg * ROWB + (32 * ct + c) * 2) = f2bf(e);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        f32x16 rs = {0};
-#pragma unroll
-        for (int ks = 0; ks < COLS / 16; ++ks)
-            rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tP + c * ROWB + (ks * 16 + hh * 8) * 2), ones, rs, 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = __builtin_amdgcn_rcpf(rs[r]);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gg = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pv = gg < H ? am[ct][r] * rs[r] : 0.f;
-                const bf16_t phi = f2bf(pv);
-                *(bf16_t*)(tP + gg * ROWB + (32 * ct + c) * 2) = phi;
-                *(bf16_t*)(tL + gg * ROWB + (32 * ct + c) * 2) = f2bf(pv - bf2f(phi));
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            f32x16 rr = {0};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 ph = tr_frag32<ROWB>(tP, 16 * s, 32 * ct, lane), pl = tr_frag32<ROWB>(tL, 16 * s, 32 * ct, lane);
-                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWh[s], ph, rr, 0, 0, 0);
-                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWh[s], pl, rr, 0, 0, 0);
-                rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aWl2[s], ph, rr, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gg = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                *(bf16_t*)(tH + gg * ROWB + (32 * ct + c) * 2) = f2bf(rr[r]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < H * (COLS / 8); idx += 64) {
-            const int h = idx / (COLS / 8), ck = idx - h * (COLS / 8);
-            const u32x4 rv = *(const u32x4*)(tH + h * ROWB + ck * 16);
-            // R stays in LDS for the value product: the row's f32 scores are dead, bf16 R takes the first half of their slot
-            *(u32x4*)((char*)(Sall + ((size_t)h * RT + q) * COLS) + ck * 16) = rv;
-            if (ck < nchunk) {
-                const int64_t dst = base + h * hs + ck * 8;
-                if (p.P) *(u32x4*)(p.P + dst) = *(const u32x4*)(tP + h * ROWB + ck * 16);
-                *(u32x4*)(p.R + dst) = rv;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- C: ctx_h = R_h V_h -------------------------------------------------------------------------------------
-    char* vt = tH;                                          // the three private tiles as one k-major V_h image [COLS][VROWB]
-    for (int h = wave; h < H; h += 4) {
-        __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < COLS * (HD / 8); idx += 64) {
-            const int j = idx / (HD / 8), ck = idx - j * (HD / 8);
-            const int jj = min(j, p.N - 1);                  // rows past N meet R = 0 (finite values are all that is needed)
-            *(u32x4*)(vt + j * VROWB + ck * 16) = *(const u32x4*)(qb + (int64_t)jj * p.ld + 2 * p.D + h * HD + ck * 8);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        f32x4 oc[DT];
-#pragma unroll
-        for (int d = 0; d < DT; ++d) oc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* rrow = (const char*)(Sall + ((size_t)h * RT + min(fr, RT - 1)) * COLS);
-#pragma unroll
-        for (int ks = 0; ks < COLS / 32; ++ks) {
-            if (ks * 32 >= p.Np) continue;
-            const bf16x8 pf = *(const bf16x8*)(rrow + (ks * 32 + fk) * 2);
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-                oc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VROWB>(vt, ks * 32, d * 16, lane), pf, oc[d], 0, 0, 0);
-        }
-        const int i = i0 + fr;
-        if (fr < RT && i < p.N) {
-            bf16_t* o = p.ctx + ((int64_t)b * p.N + i) * p.ldc + h * HD + g * 4;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) *(bf16x4*)(o + d * 16) = bf16x4{f2bf(oc[d][0]), f2bf(oc[d][1]), f2bf(oc[d][2]), f2bf(oc[d][3])};
-        }
-    }
-}
-
-
 struct SoftmaxBwd {
     const bf16_t* dR;        // [B,H,N,Np]
     const bf16_t* P;         // [B,H,N,Np] (post-softmax, pre conv_w)
@@ -1307,8 +1087,7 @@ extern "C" int dclip_attn_softmax_fwd(const float* S, const float* Wl, const flo
     TraceScope tr(DCLIP_TRACE_ATTN, Wl ? 4.0 * B * H * H * N * N : 0.0, (4.0 + 2.0 + (P ? 2.0 : 0.0)) * B * H * N * Np, stream, (int)(B * H), (int)N, (int)H, 5);
     const int ns = N > 64 ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
-    static const int mfma_mode = [] { const char* e = getenv("DCLIP_SOFTMAX_MFMA"); return e ? atoi(e) : 1; }();
-    if (Wl && !causal && mfma_mode && H > 12) {     // H <= 12: the 144-FMA register mix is faster than 32-row MFMA tiles (measured)
+    if (Wl && !causal && H > 12) {     // H <= 12: the 144-FMA register mix is faster than 32-row MFMA tiles (measured)
         int blocks = (int)((B * N + 3) / 4);
         if (blocks > 512) blocks = 512;              // persistent waves: constant fragments / LDS zero-fill amortised over rows
         const size_t lds = (size_t)4 * 3 * 32 * (64 * ns * 2 + 16);
@@ -1318,33 +1097,6 @@ extern "C" int dclip_attn_softmax_fwd(const float* S, const float* Wl, const flo
         SM_DISPATCH_H(H, ns, hipLaunchKernelGGL((attn_softmax_fwd_kernel<HH, NSS>), grid, dim3(256), 0, st, p));
     }
     return dclip_check_launch("dclip_attn_softmax_fwd");
-}
-
-extern "C" int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* S, void* P, void* R,
-                                      void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t Np, int64_t hd, float scale,
-                                      void* stream) {
-    DCLIP_REQUIRE(qkv && Wl && Ww && R && ctx && B > 0 && N > 0 && N <= NMAX && Np % 8 == 0 && Np >= N, "dclip_attn_student_fwd: bad argument");
-    DCLIP_REQUIRE(ld % 8 == 0 && ldc % 4 == 0, "dclip_attn_student_fwd: rows must be 16-byte (qkv) / 8-byte (ctx) aligned");
-    DCLIP_REQUIRE(dclip_attn_student_fwd_supported(H, N, hd), "dclip_attn_student_fwd: unsupported shape H=%ld N=%ld hd=%ld (see dclip_attn_student_fwd_supported)",
-                  (long)H, (long)N, (long)hd);
-    StudentAttn p{(const bf16_t*)qkv, ld, Wl, Ww, (bf16_t*)S, (bf16_t*)P, (bf16_t*)R, (bf16_t*)ctx, ldc, (int)B, (int)N, (int)Np,
-                  (int)(H * hd), scale};
-    hipStream_t st = (hipStream_t)stream;
-    if (H == 24) {
-        constexpr int RT = 16;
-        const size_t lds = (size_t)24 * RT * 64 * 4 + (size_t)4 * 3 * 32 * (64 * 2 + 16);
-        hipLaunchKernelGGL((attn_student_fwd_kernel<24, 1, 32>), dim3((unsigned)(B * ((N + RT - 1) / RT))), dim3(256), lds, st, p);
-    } else {
-        constexpr int RT = 8;
-        const size_t lds = (size_t)12 * RT * 128 * 4 + (size_t)4 * 3 * 32 * (128 * 2 + 16);
-        hipLaunchKernelGGL((attn_student_fwd_kernel<12, 2, 64>), dim3((unsigned)(B * ((N + RT - 1) / RT))), dim3(256), lds, st, p);
-    }
-    return dclip_check_launch("dclip_attn_student_fwd");
-}
-
-// shapes with a fused instantiation: the two students of the shipped configs (24 heads x 32, <= 64 tokens ; 12 heads x 64, 65..128)
-extern "C" int dclip_attn_student_fwd_supported(int64_t H, int64_t N, int64_t hd) {
-    return (H == 24 && hd == 32 && N <= 64) || (H == 12 && hd == 64 && N > 64 && N <= 128);
 }
 
 extern "C" int dclip_attn_softmax_bwd(const void* dR, const void* P, const void* S, int scores_bf16, const float* Wl, const float* Ww,

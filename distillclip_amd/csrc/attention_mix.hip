@@ -181,14 +181,8 @@ extern "C" int dclip_attn_mix_fwd(const void* qkv, int64_t ld, const float* Wl, 
     const dim3 grid((unsigned)((B * QT + 3) / 4));
     const double el = (double)B * H * N * Np;
     TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd + 8.0 * el * H, 2.0 * el + 4.0 * B * N * H * hd, stream, (int)(B * H), (int)N, (int)hd, 7);
-    static const int occ = [] { const char* e = getenv("DCLIP_MIX_OCC"); return e ? atoi(e) : 2; }();
-    if (occ == 1) {
-        MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_, 1>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
-                                               (hipStream_t)stream, p));
-    } else {
-        MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_, 2>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
-                                               (hipStream_t)stream, p));
-    }
+    MIX_DISPATCH(H, hd, hipLaunchKernelGGL((attn_mix_fwd_kernel<HH, HD_, 2>), grid, dim3(256), (size_t)4 * amix::fwd_lds_per_wave<CC>(),
+                                           (hipStream_t)stream, p));
     return dclip_check_launch("dclip_attn_mix_fwd");
 }
 

@@ -3,7 +3,7 @@
 #include <stdio.h>
 #include "common.h"
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[1024] = "";
 
 void dclip_set_error(const char* fmt, ...) {
     va_list ap;
@@ -12,7 +12,60 @@ void dclip_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int dclip_version(void) { return 3; }
+extern "C" int dclip_version(void) { return 4; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Which HIP runtime is this library bound to, and is it the only one in the process?  (include/dclip.h, "Load order".)  PyTorch-ROCm
+// ships a libamdhip64 of its own and asks for it by a different name than this library's DT_NEEDED entry, so a process that maps this
+// library first and torch second holds two runtimes with separate device state; kernels of the second one then fail with HIP's
+// "no ROCm-capable device is detected", which says nothing about the cause.
+// ---------------------------------------------------------------------------------------------------------------
+#include <string.h>
+#include <string>
+#include <vector>
+static std::vector<std::string> mapped_hip_runtimes() {
+    std::vector<std::string> out;
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return out;
+    char line[1024];
+    while (fgets(line, sizeof(line), f)) {
+        const char* p = strstr(line, "libamdhip64");
+        if (!p) continue;
+        const char* path = strchr(line, '/');
+        if (!path) continue;
+        std::string s(path);
+        while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+        bool seen = false;
+        for (const auto& o : out) seen = seen || o == s;
+        if (!seen) out.push_back(s);
+    }
+    fclose(f);
+    return out;
+}
+
+void dclip_explain_hip_error(const char* what, int hip_error, const char* hip_text) {
+    const std::vector<std::string> rt = mapped_hip_runtimes();
+    if (rt.size() > 1) {
+        std::string all;
+        for (const auto& r : rt) all += (all.empty() ? "" : ", ") + r;
+        dclip_set_error("%s: %s — %zu HIP runtimes are mapped in this process (%s): libdistillclip_hip.so was loaded before the one PyTorch ships; "
+                        "import torch (or load its libamdhip64) BEFORE this library (include/dclip.h, Load order)", what, hip_text, rt.size(), all.c_str());
+    } else if (hip_error == (int)hipErrorNoDevice || hip_error == (int)hipErrorInvalidDevice) {
+        dclip_set_error("%s: %s — the HIP runtime %s sees no usable device (is a GPU visible to this process? HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)",
+                        what, hip_text, rt.empty() ? "(not found in /proc/self/maps)" : rt[0].c_str());
+    } else {
+        dclip_set_error("%s: %s", what, hip_text);
+    }
+}
+
+extern "C" int dclip_runtime_check(void) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    const std::vector<std::string> rt = mapped_hip_runtimes();
+    if (rt.size() > 1) { dclip_explain_hip_error("dclip_runtime_check", (int)e, e == hipSuccess ? "more than one HIP runtime" : hipGetErrorString(e)); return DCLIP_ELAUNCH; }
+    if (e != hipSuccess || n <= 0) { dclip_explain_hip_error("dclip_runtime_check", (int)(e == hipSuccess ? hipErrorNoDevice : e), e == hipSuccess ? "no device" : hipGetErrorString(e)); return DCLIP_ELAUNCH; }
+    return DCLIP_OK;
+}
 extern "C" const char* dclip_arch(void) { return "gfx950"; }
 extern "C" const char* dclip_last_error_string(void) { return g_err; }
 

@@ -7,6 +7,8 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -42,10 +44,12 @@ struct TraceScope {
 #define DCLIP_TRACE_ATTN 4
 #define DCLIP_TRACE_LN_BWD 5
 
+// a failed launch, in words (capi.cpp): names a second HIP runtime in the process or an invisible device where that is the cause
+void dclip_explain_hip_error(const char* what, int hip_error, const char* hip_text);
 static inline int dclip_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        dclip_set_error("%s: %s", what, hipGetErrorString(e));
+        dclip_explain_hip_error(what, (int)e, hipGetErrorString(e));
         return DCLIP_ELAUNCH;
     }
     return DCLIP_OK;
@@ -99,6 +103,24 @@ __device__ __forceinline__ void gelu_erf_both_f(float x, float& g, float& dg) {
     const float cdf = x >= 0.f ? 1.f - 0.5f * tail : 0.5f * tail;
     g = x * cdf;
     dg = fmaf(x * phi, 0.3989422804014327f, cdf);
+}
+
+// gelu'(x) saved for the backward as 8-bit fixed point (DCLIP_ACT_GELU_SAVE writes it, DCLIP_ACT_MULAUX multiplies by it): the
+// derivative of the exact GELU lies in [-0.1289, 1.1289]; code q = rint((g' - DG_LO) / DG_STEP) in 0..255, value DG_LO + q DG_STEP.
+// |error| <= DG_STEP / 2 = 2.5e-3: on dz = dy g'(z) the same relative L2 error as a bf16 g' (DESIGN.md section 7), at half the bytes.
+#define DCLIP_DG_LO (-0.13f)
+#define DCLIP_DG_STEP (1.26f / 255.f)
+__device__ __forceinline__ unsigned dg_pack4(float a, float b, float c, float d) {
+    const float inv = 255.f / 1.26f, off = 0.13f * (255.f / 1.26f);
+    unsigned r = 0;
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a, inv, off)), 0, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(b, inv, off)), 1, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(c, inv, off)), 2, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(d, inv, off)), 3, r);
+    return r;
+}
+__device__ __forceinline__ float dg_unpack(unsigned w, int byte) {      // byte: compile-time constant 0..3
+    return fmaf((float)((w >> (8 * byte)) & 0xffu), DCLIP_DG_STEP, DCLIP_DG_LO);
 }
 
 // XCD-aware, bijective remap of a linear workgroup id: blocks that share an XCD (same id % 8 under the

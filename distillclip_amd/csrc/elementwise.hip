@@ -19,6 +19,20 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ s, 
     }
 }
 
+// f16 -> f32 (hidden states of the frozen teacher leave its fp16 residual stream as f32 tensors)
+__global__ __launch_bounds__(256) void cast_f16_f32_kernel(const _Float16* __restrict__ s, float* __restrict__ d, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            const f16x4 v = *(const f16x4*)(s + i);
+            *(float4*)(d + i) = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        } else {
+            for (int64_t j = i; j < n; ++j) d[j] = (float)s[j];
+        }
+    }
+}
+
 // W f32 [R,C] -> Wb bf16 [R,C] and Wt bf16 [C,R]; 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wb,
                                                              bf16_t* __restrict__ Wt, int R, int C) {
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
     unsafeAtomicAdd(o, s.x); unsafeAtomicAdd(o + 1, s.y); unsafeAtomicAdd(o + 2, s.z); unsafeAtomicAdd(o + 3, s.w);
 }
 
-template <bool OUT_F32>
+template <int OUT>      // 0 bf16, 1 f32, 2 f16
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, int id_stride,
                                                            const float* __restrict__ table, const float* __restrict__ pos,
                                                            void* __restrict__ out, int rows, int N, int D) {
@@ -181,7 +195,8 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
             const float4 pv = *(const float4*)(pos + (int64_t)(r % N) * D + q * 4);
             v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
         }
-        if (OUT_F32) *(float4*)((float*)out + (int64_t)r * D + q * 4) = v;
+        if (OUT == 1) *(float4*)((float*)out + (int64_t)r * D + q * 4) = v;
+        else if (OUT == 2) *(f16x4*)((_Float16*)out + (int64_t)r * D + q * 4) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         else *(bf16x4*)((bf16_t*)out + (int64_t)r * D + q * 4) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
     }
 }
@@ -374,6 +389,13 @@ extern "C" int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* str
     return dclip_check_launch("dclip_cast_bf16");
 }
 
+extern "C" int dclip_cast_f16_f32(const void* src, float* dst, int64_t n, void* stream) {
+    DCLIP_REQUIRE(src && dst && n > 0, "dclip_cast_f16_f32: bad argument");
+    DCLIP_REQUIRE(((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 16) == 0, "dclip_cast_f16_f32: misaligned buffer");
+    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, n);
+    return dclip_check_launch("dclip_cast_f16_f32");
+}
+
 extern "C" int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream) {
     DCLIP_REQUIRE(W && (Wb || Wt) && R > 0 && C > 0, "dclip_cast_transpose_bf16: bad argument");
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
@@ -445,11 +467,13 @@ extern "C" int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_
 }
 
 extern "C" int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const float* table, const float* pos, void* out,
-                                  int out_f32, int64_t rows, int64_t N, int64_t D, void* stream) {
+                                  int out_dtype, int64_t rows, int64_t N, int64_t D, void* stream) {
     DCLIP_REQUIRE(ids && table && out && rows > 0 && N > 0 && id_stride >= N && D > 0 && D % 4 == 0, "dclip_embed_gather: bad argument");
     const dim3 grid(grid_for(rows * D / 4));
-    if (out_f32) hipLaunchKernelGGL((embed_gather_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
-    else hipLaunchKernelGGL((embed_gather_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
+    DCLIP_REQUIRE(out_dtype >= 0 && out_dtype <= 2, "dclip_embed_gather: bad output dtype %d (0 bf16, 1 f32, 2 f16)", out_dtype);
+    if (out_dtype == 1) hipLaunchKernelGGL((embed_gather_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
+    else if (out_dtype == 2) hipLaunchKernelGGL((embed_gather_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
+    else hipLaunchKernelGGL((embed_gather_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, ids, (int)id_stride, table, pos, out, (int)rows, (int)N, (int)D);
     return dclip_check_launch("dclip_embed_gather");
 }
 

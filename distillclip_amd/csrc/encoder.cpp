@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <new>
 #include <vector>
 #include "common.h"
@@ -117,15 +118,19 @@ bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
 // workspace layout
 // ------------------------------------------------------------------------------------------------------------
 struct ExecSave {          // per block execution (student training)
-    float* x_mid; float* mean1; float* rstd1; float* mean2; float* rstd2;
-    bf16_t *h1, *qkv, *P, *Rm, *ctx, *h2, *z, *u;
+    void* x_mid;           // residual stream after the attention branch: f32 (students), f16 (the frozen teacher)
+    float* mean1; float* rstd1; float* mean2; float* rstd2;
+    bf16_t *h1, *qkv, *P, *Rm, *ctx, *h2, *u;
+    uint8_t* z;            // gelu'(fc1 pre-activation) as 8-bit fixed point (DCLIP_ACT_GELU_SAVE -> DCLIP_ACT_MULAUX)
     float* S;
     float* stats;          // [B, H, N] log-sum-exp rows of the register-resident attention path
 };
 
 struct Work {
     // persistent
-    std::vector<float*> X;                 // residual stream: X[0] embedding output .. X[LR]
+    std::vector<void*> X;                  // residual stream: X[0] embedding output .. X[LR]; f32 for students, f16 for the frozen
+                                           // teacher (what the reference's `precision: 16` autocast keeps there: _common.py:14-20, :124-125)
+    bool h16;
     std::vector<ExecSave> ex;
     bf16_t* patches;                       // image: [M, K] ; compressed text: [M, rank]
     float* tok_table;                      // [N, D]
@@ -133,8 +138,7 @@ struct Work {
     float *meanf, *rstdf;                  // final LN stats [B]
     bf16_t* hf;                            // [B, D]
     // temporaries
-    float* x0;                             // teacher image pre-ln_pre tokens
-    bf16_t* delta;                         // [M, D] output of a block execution's second MLP linear while its residual add is pending
+    void* x0;                              // teacher image pre-ln_pre tokens (f16)
     float* G; bf16_t* Gb;                  // residual-stream gradient
     // gradients that are wgrad operands keep one slot per repeat: the R executions of a weight-shared block feed ONE
     // wgrad GEMM over R * M rows (half the launches and half the f32 atomic traffic at R = 2)
@@ -158,9 +162,10 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     w.ex.assign(nex, ExecSave{});
     // teacher / inference: a single ping-pong set reused by every block
     ExecSave shared{};
-    float* xs = nullptr;
+    void* xs = nullptr;
+    w.h16 = !p.student;
     if (!save) {
-        xs = b.take<float>(M * D);
+        xs = w.h16 ? (void*)b.take<_Float16>(M * D) : (void*)b.take<float>(M * D);
         shared.x_mid = xs;   // in-place residual stream
         shared.h1 = b.take<bf16_t>(M * D); shared.qkv = b.take<bf16_t>(M * 3 * D);
         shared.S = b.take<float>(SN); shared.P = (p.student && p.c.head_mix) ? b.take<bf16_t>(SN) : nullptr;
@@ -169,7 +174,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         shared.ctx = b.take<bf16_t>(M * D); shared.h2 = shared.h1; shared.z = nullptr; shared.u = b.take<bf16_t>(M * F);
         shared.mean1 = shared.rstd1 = shared.mean2 = shared.rstd2 = nullptr;
     }
-    for (int e = 0; e <= nex; ++e) w.X[e] = save ? b.take<float>(M * D) : xs;
+    for (int e = 0; e <= nex; ++e) w.X[e] = save ? (void*)b.take<float>(M * D) : xs;
     for (int e = 0; e < nex; ++e) {
         if (!save) { w.ex[e] = shared; continue; }
         ExecSave& s = w.ex[e];
@@ -178,7 +183,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
         s.qkv = b.take<bf16_t>(M * 3 * D);
         s.S = b.take<float>(SN); s.P = b.take<bf16_t>(SN); s.Rm = p.c.head_mix ? b.take<bf16_t>(SN) : s.P;
         s.stats = b.take<float>(B * p.H * N);
-        s.z = b.take<bf16_t>(M * F);
+        s.z = b.take<uint8_t>(M * F);
         if (e % p.R == 0) {
             // the wgrad operands (inputs of the four linears) of a block's R executions lie back to back: [R][M, .]
             bf16_t* h1 = b.take<bf16_t>(p.R * M * D); bf16_t* ctx = b.take<bf16_t>(p.R * M * D);
@@ -194,8 +199,7 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     w.pick = b.take<int32_t>(B);
     w.meanf = b.take<float>(B); w.rstdf = b.take<float>(B);
     w.hf = b.take<bf16_t>(B * D);
-    w.x0 = (!p.student && p.image) ? b.take<float>(M * D) : nullptr;
-    w.delta = b.take<bf16_t>(M * D);
+    w.x0 = (!p.student && p.image) ? (void*)b.take<_Float16>(M * D) : nullptr;
     if (save) {
         w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
         w.gb_f2 = b.take<bf16_t>(p.R * M * D); w.gb_pr = b.take<bf16_t>(p.R * M * D);
@@ -217,15 +221,6 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
 
 inline const float* PF(const void* const* params, int i) { return (const float*)params[i]; }
 
-// DCLIP_FUSED_ATTN=1 (opt-in): head-mixing students of the shipped shapes run the attention forward as ONE kernel, which saves the
-// pre-mix scores as bf16 (forward and backward must agree on that format, hence one predicate for both).  Off by default: the
-// first version of that kernel moves 43 % fewer bytes but, at one 153 KiB workgroup per CU, is latency-bound (318 / 818 us
-// against 170 / 230 us for the three bandwidth-bound kernels at B = 512); see DESIGN.md section 7.
-inline bool fused_student_attn(const Plan& p, int64_t N) {
-    static const int mode = [] { const char* e = getenv("DCLIP_FUSED_ATTN"); return e ? atoi(e) : 0; }();
-    return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_student_fwd_supported(p.H, N, p.hd) != 0;
-}
-
 // Head-mixing students whose shape has an instantiation of the register-resident score stage (attention_mix.hip: both head mixes
 // on the matrix pipe) keep S, A, P, dR out of HBM; forward and backward must agree (the backward recomputes from qkv + the forward's
 // softmax statistics), hence one predicate for both.  DCLIP_ATTN_MIX=0 selects the unfused kernels (attn_nt -> softmax -> ...).
@@ -233,22 +228,6 @@ inline bool mix_attn(const Plan& p, int64_t N) {
     static const int mode = [] { const char* e = getenv("DCLIP_ATTN_MIX"); return e ? atoi(e) : 1; }();
     return mode != 0 && p.student && p.c.head_mix && !p.c.causal && dclip_attn_mix_supported(p.H, N, p.hd) != 0;
 }
-
-// The residual add behind the MLP (x = x + mlp(ln_2(x)): _common.py:125, weight_share_model.py:184) leaves the fc2 GEMM's epilogue,
-// where the f32 stream was read and re-written by 256 workgroups at once with the matrix pipe idle (25600 x 768 x 3072: 141 us
-// against 91 us with a bf16 store), and is done by the LayerNorm that opens the next block execution (dclip_layernorm_fwd_add:
-// +20 us for the extra 39 MB read and 79 MB written at streaming rate).  Same HBM bytes, ~30 us less per block execution in
-// isolation — and nothing in the four-stream step (gemm_nt -0.5 ms, ln_fwd +0.64 ms per step, throughput within noise: the other
-// towers' kernels already fill the time a residual epilogue spends waiting for HBM), while the linear's output gets rounded to
-// bf16 before the add (as the reference's fp16 autocast rounds it to fp16).  Hence OPT-IN: DCLIP_DEFER_RESIDUAL=1; the default
-// keeps the add in the GEMM epilogue.
-inline int defer_residual_mode() {
-    static const int mode = [] { const char* e = getenv("DCLIP_DEFER_RESIDUAL"); return e ? atoi(e) : 0; }();
-    return mode;
-}
-inline bool defer_mlp_residual() { return defer_residual_mode() != 0; }
-// =2 (experiment): the attention projection's add as well, done by ln_2 of the same execution
-inline bool defer_attn_residual() { return defer_residual_mode() == 2; }
 
 // split count of the wgrad contraction: minimise  rounds(tiles*s / 512 resident workgroups) * work per workgroup
 //                                                   + atomic traffic (s * P*Q*4 bytes at ~1.3 TB/s, half hidden)
@@ -269,14 +248,35 @@ inline int wsplits(int64_t M, int64_t P, int64_t Q) {
 }
 
 inline int gemm(const void* A, int64_t lda, const void* Bw, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                const float* bias, int act, const void* aux_in, void* aux_out, const float* res, int64_t ldr, int out_f32,
+                const float* bias, int act, const void* aux_in, void* aux_out, const void* res, int64_t ldr, int out_dtype,
                 int64_t row_group, const float* rowadd, void* st) {
-    return dclip_gemm_nt(A, lda, Bw, ldb, C, ldc, M, N, K, 1.f, bias, act, aux_in, aux_out, res, ldr, out_f32, row_group, rowadd, nullptr, st);
+    return dclip_gemm_nt(A, lda, Bw, ldb, C, ldc, M, N, K, 1.f, bias, act, aux_in, aux_out, res, ldr, out_dtype, row_group, rowadd, nullptr, st);
+}
+
+// LayerNorm over rows of the tower's residual stream (f32, or f16 for the frozen teacher)
+inline int ln_stream(bool h16, const void* x, int64_t ldx, const int32_t* ridx, const float* g, const float* b, void* y, int64_t ldy, int out_dtype,
+                     float* mean, float* rstd, int64_t M, int64_t D, void* st) {
+    if (h16) return dclip_layernorm_fwd_f16(x, ldx, ridx, g, b, y, ldy, out_dtype, mean, rstd, M, D, 1e-5f, st);
+    return dclip_layernorm_fwd((const float*)x, ldx, ridx, g, b, y, ldy, out_dtype, mean, rstd, M, D, 1e-5f, st);
+}
+
+// a [M, D] piece of the residual stream as the f32 tensor the caller asked for (hidden-state / embedding export)
+inline int export_stream(bool h16, const void* src, float* dst, int64_t n, void* st) {
+    if (h16) return dclip_cast_f16_f32(src, dst, n, st);
+    if (hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {
+        dclip_set_error("dclip_encoder_forward: hidden-state export failed");
+        return DCLIP_ELAUNCH;
+    }
+    return DCLIP_OK;
 }
 
 }  // namespace
 
-struct dclip_encoder { Plan p; };
+// seeded: the workspace whose backward seeds (residual-gradient accumulator, its bf16 copy, the last execution's fc2 operand slot)
+// the most recent training forward of this handle left cleared — the only mutable word of the handle.  dclip_encoder_backward
+// consumes it; a backward that does not find its workspace there (a second backward on one forward, a retry after a failed one,
+// another workspace in between) clears the seeds itself, so the call is self-contained whatever the caller does.
+struct dclip_encoder { Plan p; mutable std::atomic<void*> seeded{nullptr}; };
 
 extern "C" dclip_encoder* dclip_encoder_create(const dclip_encoder_cfg* cfg) {
     if (!cfg) { dclip_set_error("dclip_encoder_create: null cfg"); return nullptr; }
@@ -354,7 +354,7 @@ static int clear_backward_seeds(const Plan& p, const Work& w, int64_t M, void* s
     bf16_t* gb_last = w.gb_f2 + (int64_t)(p.R - 1) * M * D;
     if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(w.Gb, 0, (size_t)M * D * 2, hs) != hipSuccess ||
         hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) {
-        dclip_set_error("dclip_encoder_forward: memset failed");
+        dclip_set_error("dclip_encoder: clearing the backward seeds failed");
         return DCLIP_ELAUNCH;
     }
     return DCLIP_OK;
@@ -393,29 +393,22 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
             CK(gemm(patches, p.K, W + p.w_embed, p.K, w.X[0], D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
         } else {           // params: 0 conv1 w, 1 class_embedding, 2 positional_embedding, 3 ln_pre w, 4 ln_pre b
             CK(dclip_token_table(PF(params, 2), PF(params, 1), nullptr, w.tok_table, N, D, st));
-            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
-            CK(dclip_layernorm_fwd(w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, 1, nullptr, nullptr, M, D, 1e-5f, st));
+            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, DCLIP_OUT_F16, N, w.tok_table, st));
+            CK(ln_stream(true, w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, DCLIP_OUT_F16, nullptr, nullptr, M, D, st));
         }
     } else if (p.compressed) {   // params: 0 table [V,rank], 1 linear w [D,rank], 2 linear b, 3 pos
         CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), nullptr, w.patches, 0, M, N, p.c.embed_rank, st));
         CK(dclip_token_table(PF(params, 3), nullptr, PF(params, 2), w.tok_table, N, D, st));
         CK(gemm(w.patches, p.c.embed_rank, W + p.w_embed, p.c.embed_rank, w.X[0], D, M, D, p.c.embed_rank, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
     } else {                     // params: 0 table [V,D], 1 pos [N,D]
-        CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), PF(params, 1), w.X[0], 1, M, N, D, st));
+        CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), PF(params, 1), w.X[0], w.h16 ? DCLIP_OUT_F16 : DCLIP_OUT_F32, M, N, D, st));
     }
 
     // optional export of the post-positional-embedding tokens (reference ControlOutput.need_emb: _common.py:204-206 captures
     // them BEFORE ln_pre; text_encoder.py:66-67 ; weight_share_model.py:350,490)
-    if (emb_out) {
-        const float* src = (!p.student && p.image) ? w.x0 : w.X[0];
-        if (hipMemcpyAsync(emb_out, src, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {
-            dclip_set_error("dclip_encoder_forward: embedding export failed");
-            return DCLIP_ELAUNCH;
-        }
-    }
+    if (emb_out) CK(export_stream(w.h16, (!p.student && p.image) ? w.x0 : w.X[0], emb_out, M * D, st));
 
     // ---- blocks --------------------------------------------------------------------------------------------
-    const float* pending_x = nullptr;      // x_mid of the previous execution while its MLP residual add is pending (w.delta)
     for (int ei = 0; ei < nex; ++ei) {
         const int l = ei / p.R, r = ei % p.R;
         const auto& bw = p.bw[l];
@@ -431,14 +424,10 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
             n1w = PF(params, tb.ln1w); n1b = PF(params, tb.ln1b); n2w = PF(params, tb.ln2w); n2b = PF(params, tb.ln2b);
             bq = PF(params, tb.inb); bp = PF(params, tb.outb); b1 = PF(params, tb.fcb); b2 = PF(params, tb.prb);
         }
-        float* xin = w.X[ei];
-        float* xout = w.X[ei + 1];
-        if (pending_x) {   // the previous execution's MLP output is still to be added: xin = x_mid(previous) + delta, then ln_1
-            CK(dclip_layernorm_fwd_add(pending_x, D, w.delta, D, xin, D, n1w, n1b, s.h1, D, s.mean1, s.rstd1, M, D, 1e-5f, st));
-            pending_x = nullptr;
-        } else {
-            CK(dclip_layernorm_fwd(xin, D, nullptr, n1w, n1b, s.h1, D, 0, s.mean1, s.rstd1, M, D, 1e-5f, st));
-        }
+        void* xin = w.X[ei];
+        void* xout = w.X[ei + 1];
+        const int sdt = w.h16 ? DCLIP_OUT_F16 : DCLIP_OUT_F32;        // dtype of the residual stream
+        CK(ln_stream(w.h16, xin, D, nullptr, n1w, n1b, s.h1, D, DCLIP_OUT_BF16, s.mean1, s.rstd1, M, D, st));
         CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         if (!training && !wl) {
             // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
@@ -447,44 +436,29 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
             if (wl && mix_attn(p, N)) {
                 CK(dclip_attn_mix_fwd(s.qkv, 3 * D, wl, ww, s.Rm, s.stats, B, H, N, Np, hd, scale, st));
                 CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, 1, st));
-            } else if (wl && fused_student_attn(p, N)) {
-                CK(dclip_attn_student_fwd(s.qkv, 3 * D, wl, ww, s.S, s.P, s.Rm, s.ctx, D, B, H, N, Np, hd, scale, st));
             } else {
                 CK(dclip_attn_nt(s.qkv, 3 * D, s.qkv + D, 3 * D, s.S, 1, B, H, N, Np, hd, scale, st));
                 CK(dclip_attn_softmax_fwd(s.S, wl, ww, wl ? s.P : nullptr, s.Rm, B, H, N, Np, p.c.causal, st));
                 CK(dclip_attn_nn(s.Rm, s.qkv + 2 * D, 3 * D, s.ctx, D, B, H, N, Np, hd, 1.f, 0, st));
             }
         }
-        if (defer_attn_residual()) {
-            CK(gemm(s.ctx, D, W + bw.proj, D, w.delta, D, M, D, D, bp, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-            CK(dclip_layernorm_fwd_add(xin, D, w.delta, D, s.x_mid, D, n2w, n2b, s.h2, D, s.mean2, s.rstd2, M, D, 1e-5f, st));
-        } else {
-            CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, 1, 0, nullptr, st));
-            CK(dclip_layernorm_fwd(s.x_mid, D, nullptr, n2w, n2b, s.h2, D, 0, s.mean2, s.rstd2, M, D, 1e-5f, st));
-        }
+        CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, sdt, 0, nullptr, st));
+        CK(ln_stream(w.h16, s.x_mid, D, nullptr, n2w, n2b, s.h2, D, DCLIP_OUT_BF16, s.mean2, s.rstd2, M, D, st));
         CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
-        // every execution but the last hands its MLP output to the next execution's ln_1 (defer_mlp_residual); the last one, and any
-        // execution whose hidden state is exported, adds it in the GEMM epilogue so that X[ei + 1] exists when this loop ends
-        if (defer_mlp_residual() && ei + 1 < nex && !(rep_out && rep_out[ei])) {
-            CK(gemm(s.u, F, W + bw.fc2, F, w.delta, D, M, D, F, b2, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-            pending_x = s.x_mid;
-        } else {
-            CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, 1, 0, nullptr, st));
-        }
+        CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, sdt, 0, nullptr, st));
         // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
-        if (rep_out && rep_out[ei] &&
-            hipMemcpyAsync(rep_out[ei], xout, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess) {
-            dclip_set_error("dclip_encoder_forward: hidden-state export failed");
-            return DCLIP_ELAUNCH;
-        }
+        if (rep_out && rep_out[ei]) CK(export_stream(w.h16, xout, rep_out[ei], M * D, st));
     }
 
     // ---- final norm + projection on the picked token only (class token / EOT = argmax of the ids) ----------------
     CK(dclip_pick_index(p.image ? nullptr : (const int64_t*)input, p.N, w.pick, B, N, st));
     const int f = p.p_final;
-    CK(dclip_layernorm_fwd(w.X[nex], D, w.pick, PF(params, f), PF(params, f + 1), w.hf, D, 0, w.meanf, w.rstdf, B, D, 1e-5f, st));
+    CK(ln_stream(w.h16, w.X[nex], D, w.pick, PF(params, f), PF(params, f + 1), w.hf, D, DCLIP_OUT_BF16, w.meanf, w.rstdf, B, D, st));
     CK(gemm(w.hf, D, W + p.w_head, D, last_representation, E, B, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
-    if (training) CK(clear_backward_seeds(p, w, M, st));
+    if (training) {
+        CK(clear_backward_seeds(p, w, M, st));
+        e->seeded.store(workspace, std::memory_order_release);
+    }
     return DCLIP_OK;
 }
 
@@ -521,7 +495,7 @@ extern "C" int dclip_encoder_last_layer_output(const dclip_encoder* e, int64_t B
     const bf16_t* W = (const bf16_t*)wcache;
     const int64_t M = B * p.N, D = p.D, E = p.E;
     const int nex = p.L * p.R, f = p.p_final;
-    CK(dclip_layernorm_fwd(w.X[nex], D, nullptr, PF(params, f), PF(params, f + 1), scratch, D, 0, nullptr, nullptr, M, D, 1e-5f, st));
+    CK(ln_stream(w.h16, w.X[nex], D, nullptr, PF(params, f), PF(params, f + 1), scratch, D, DCLIP_OUT_BF16, nullptr, nullptr, M, D, st));
     CK(gemm(scratch, D, W + p.w_head, D, out, E, M, E, D, p.student ? PF(params, f + 3) : nullptr, 0, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, st));
     return DCLIP_OK;
 }
@@ -544,7 +518,12 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
     auto GR = [&](int i) -> float* { return (float*)grads[i]; };
     hipStream_t hs = (hipStream_t)st;
 
-    // (w.G, w.Gb and the last execution's fc2 operand slot were cleared at the end of the training forward: clear_backward_seeds)
+    // w.G, w.Gb and the last execution's fc2 operand slot were cleared at the end of the training forward of THIS workspace
+    // (clear_backward_seeds) unless a backward has consumed them since: then they are cleared here
+    {
+        void* expect = workspace;
+        if (!e->seeded.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel)) CK(clear_backward_seeds(p, w, M, st));
+    }
     // ---- head + final norm -----------------------------------------------------------------------------------
     const int f = p.p_final;
     CK(dclip_cast_bf16(d_last_representation, w.dout, B * E, st));
@@ -555,7 +534,7 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
     // linear that wrote into that residual stream (fc2 of the previous execution / attn.proj of this one)
     const int R = p.R;
     bf16_t* gb_last = w.gb_f2 + (int64_t)(R - 1) * M * D;            // fc2 of the last execution reads slot R - 1
-    CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
+    CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
                            GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
     // gradient bucket 0 (final norm + head) is complete: every launch that writes it is enqueued on `st`
     if (on_bucket) on_bucket(cb_user, 0);
@@ -583,7 +562,7 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
         if (r == 0 && GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(sb.f2w), F, MR, D, F, wsplits(MR, D, F), w.tn_ws, w.tn_ws_bytes, st));
         if (r == 0 && GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(sb.f1w), D, MR, F, D, wsplits(MR, F, D), w.tn_ws, w.tn_ws_bytes, st));
         CK(gemm(dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(sr.n2w), GR(sr.n2b),
+        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(sr.n2w), GR(sr.n2b),
                                GR(sb.prb), M, D, st));
         // attention: x_mid = x_in + proj(attn(LN1(x_in)))
         if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), w.tn_ws, w.tn_ws_bytes, st));
@@ -597,7 +576,7 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
             CK(dclip_attn_mix_bwd(s.qkv, 3 * D, dctx, D, wl, ww, s.stats, w.dS, gl, gw, w.mix_ws, w.mix_ws_bytes, B, H, N, Np, hd, scale, st));
         } else {
             CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));               // dR = dO V^T
-            CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, (wl && fused_student_attn(p, N)) ? 1 : 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
+            CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
                                       wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
         }
         CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dQ = dS K
@@ -607,7 +586,7 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
         CK(gemm(dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         // the bf16 residual gradient leaving this execution is the fc2 operand of the previous one (slot of its repeat index)
         bf16_t* gb_next = ei > 0 ? w.gb_f2 + (int64_t)((ei - 1) % R) * M * D : w.Gb;
-        CK(dclip_layernorm_bwd(w.dh, D, 0, w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(sr.n1w), GR(sr.n1b),
+        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(sr.n1w), GR(sr.n1b),
                                ei > 0 ? GR(sblock(p, (ei - 1) / p.R).f2b) : nullptr, M, D, st));
         // block l's gradients (shared weights: both repeats; its fc2 bias also collects from block l + 1's first LayerNorm
         // backward, which ran earlier) are complete after its first execution's backward: bucket 1 + (L - 1 - l)

@@ -10,8 +10,6 @@
 // st_16x32 XOR swizzle (byte ^= ((byte >> 9) & 1) << 5) applied on the SOURCE address and again on the
 // ds_read_b128 address (guide: cdna_hip_programming.md §5 "LDS swizzle", rule 21).
 
-#include <mutex>
-#include <unordered_map>
 #include "gemm_common.h"
 #include <atomic>
 
@@ -41,7 +39,7 @@ __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ G, int6
     }
 }
 
-template <int ACT, bool OUT_F32>
+template <int ACT, int OUT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -138,54 +136,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
         }
         const int64_t o = (int64_t)row * p.ldc + col;
-        if (ACT != 5 && p.aux_out) {
-            bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
-            *(bf16x8*)(p.aux_out + o) = z;
-        }
-        if (ACT == 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(v[e]);
-        }
-        if (ACT == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-        }
-        if (ACT == 3) {
-            const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf2f(z[e]));
-        }
-        if (ACT == 4) {
-            const bf16x8 z = *(const bf16x8*)(p.aux_in + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= bf2f(z[e]);
-        }
-        if (ACT == 5) {
-            bf16x8 dz;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float g, dg;
-                gelu_erf_both_f(v[e], g, dg);
-                v[e] = g; dz[e] = f2bf(dg);
-            }
-            if (p.aux_out) *(bf16x8*)(p.aux_out + o) = dz;
-        }
-        if (p.residual) {
-            const float* rp = p.residual + (int64_t)row * p.ldr + col;
-            const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
-        if (OUT_F32) {
-            float* cp = (float*)p.C + o;
-            *(float4*)cp = float4{v[0], v[1], v[2], v[3]};
-            *(float4*)(cp + 4) = float4{v[4], v[5], v[6], v[7]};
-        } else {
-            bf16x8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
-            *(bf16x8*)((bf16_t*)p.C + o) = ov;
+        {   // the per-unit epilogue of the large kernels, every optional operand a run-time test (MODE 0); the side operands are loaded here
+            EpiSide sd;
+            epilogue_load_side<ACT, OUT>(p, o, (int64_t)row * p.ldr + col, sd);
+            float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, unused[8];
+            GemmNT q = p;
+            q.alpha = 1.f; q.row_group = 0; q.colsum = nullptr;        // (alpha, bias and the positional rows are applied above)
+            epilogue_vec8<ACT, OUT, 0>(q, v, row, col, o, (int64_t)row * p.ldr + col, zero, unused, sd);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
@@ -299,29 +256,7 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
-#ifdef DCLIP_NT256_NO_PERSIST     // A/B builds only (tools/diag/ab_libs.sh): the tile loop compiled out of every variant
-constexpr bool nt256_persistent(int, bool) { return false; }
-#else
-constexpr bool nt256_persistent(int act, bool out_f32) { return !out_f32 && act != 3 && act != 4; }
-#endif
-
-// ticket counters of the persistent launches: 8 (one per XCD chunk, 128 B apart) per stream — launches of one stream run one after
-// another and every launch leaves its counters at zero, launches of different streams overlap.  Zeroed once, on the stream itself.
-unsigned* nt256_tile_counters(hipStream_t st) {
-    static std::mutex mu;
-    static std::unordered_map<hipStream_t, unsigned*> per_stream;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = per_stream.find(st);
-    if (it != per_stream.end()) return it->second;
-    unsigned* c = nullptr;
-    if (hipMalloc((void**)&c, 8 * 128) != hipSuccess || hipMemsetAsync(c, 0, 8 * 128, st) != hipSuccess) c = nullptr;
-    per_stream[st] = c;                                  // (null: the launches of this stream walk their tiles statically)
-    return c;
-}
-
-// WALK: the persistent variant (a tile loop around the body).  A separate instantiation, not a run-time mode: the loop structure alone
-// costs the kernel 1.5 % in the step's single-stream probe even when every workgroup owns one tile.
-template <int ACT, bool OUT_F32, int MI, bool WALK = false>
+template <int ACT, int OUT, int MI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RH = MI / 2;                      // row tiles per phase
@@ -337,18 +272,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // tiles the 32 concurrent tiles of an XCD span every B panel (N = 3072, K = 768: 4.7 MB, more than the 4 MB L2), so B is
     // re-streamed from beyond L2 once per round; with a group whose B panels stay L2-resident an XCD streams its A rows once
     // per group and reads B once (host-side choice and traffic model: launch_nt).
-    // Persistent launches (gridDim.x < tiles, a multiple of 8): workgroup b starts with tile b and then DRAWS its next tiles from
-    // the ticket counter of its XCD's chunk (b & 7), i.e. in the order the hardware dispatcher would have handed them out — a static
-    // b, b + grid, ... walk lets the slowest workgroup's six tiles set the launch time (39424 x 3072 x 768: -5 %).  The operands of the
-    // NEXT tile's first K-tile and a half are requested when the epilogue of the current one starts (the LDS ring is idle from the
-    // main loop's last barrier on), so that only the first tile of a workgroup pays the ~3.5 k cycles of HBM latency in front of its
-    // main loop.  The ticket for tile i + 1 is drawn at the top of tile i (one lane, returning atomic, in front of the wait that
-    // opens the main loop) and handed to the other waves through an LDS word behind the operand ring.
-    // Compiled in for the bf16 epilogues without side operands only: the tile loop keeps the operand descriptors live through the
-    // epilogue, and the f32 / DGELU / MULAUX epilogues have neither the scalar nor the vector registers for that (77 spilled SGPRs and
-    // 90-255 spilled VGPRs when tried) — their launches in the step are single-round anyway (N = 512 / 768) or dominated by an
-    // HBM-bound epilogue.
-    constexpr bool PERSIST = WALK && nt256_persistent(ACT, OUT_F32);
     const int nwg = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK;
     const int nload = 4 * nk;
@@ -367,22 +290,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         m0 = tm * BMT; n0 = tn * 256;
     };
     locate(blockIdx.x);
-    // chunk of this workgroup's XCD (xcd_remap): `chunk` tiles, the launch's grid / 8 workgroups start on its first positions
-    const int xme = blockIdx.x & 7;
-    const int chunk = (nwg >> 3) + (xme < (nwg & 7) ? 1 : 0);
-    const int first_free = (int)gridDim.x >> 3;
-    unsigned* const ctr = PERSIST && p.tile_ctr && (int)gridDim.x < nwg ? p.tile_ctr + xme * 32 : nullptr;
-    int* const next_word = (int*)(smem + 2 * PAR);          // LDS word behind the ring: position of the next tile in the chunk
-    int pos = blockIdx.x >> 3;                              // position of the current tile in the chunk
-    int tiles_done = 0;
 
     f32x4 acc[MI][4];
 
     // half-tile l = 4*tile + w ; w: 0 B_lo, 1 B_hi, 2 A_up (upper row tiles of both wave groups), 3 A_dn (lower row tiles)
-    // ln: the lane index, re-issued as an opaque value at the top of every tile and of every epilogue, so that hipcc neither hoists
-    // the per-lane address arithmetic of one phase out of the tile loop nor carries it through the other phase: the main loop and
-    // the f32 epilogues each fill the 256 registers on their own (89-307 spills with a plain `lane`)
-    int ln = lane;
+    const int ln = lane;
     auto issue = [&](int l) {
         const int tile = l >> 2, w = l & 3;
         char* par = smem + (tile & 1) * PAR;
@@ -405,38 +317,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // until half-tile X has landed" = vmcnt(number of instructions issued after X)
 #define WAIT_VM2(n8, n10) do { if (MI == 10) WAIT_VMCNT(n10); else WAIT_VMCNT(n8); } while (0)
     const int npro = nload < 7 ? nload : 7;                // tile 0 entirely, tile 1: B_lo, B_hi, A_up
-    // ticket for the second tile: OLDER than the first tile's requests, so that their counted wait below covers it.  (The atomic is
-    // hidden from hipcc's wait-count pass; an extra entry in the in-order queue only makes the counted waits stricter, never laxer.)
-    unsigned ticket = 0;
-    auto draw = [&]() {
-        if (PERSIST && ctr && tid == 0)
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr), "v"(1u) : "memory");
-    };
-    draw();
     for (int l = 0; l < npro; ++l) issue(l);
     const int a_off = 2 * HT + wr * HTA;                     // this wave's A half
     const int b_off = (wc >> 1) * HT + (wc & 1) * 8 * SUB;   // this wave's B half, its 4 column blocks start at (wc&1)*4
-  for (bool first = true;; first = false) {
-    if (!first) draw();                                    // (next tile's ticket; the wait below is vmcnt(0) for every later tile)
-    ln = lane;
-    if constexpr (PERSIST) asm volatile("" : "+v"(ln));
     const int fragoff = swz((ln & 15) * 64 + (ln >> 4) * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // first tile: B_lo, B_hi, A_up of K-tile 0 landed (younger: A_dn(0), B, B, A_up(1)).  Later tiles: their requests went out
-    // before the previous epilogue's stores; vmcnt retires in issue order and the loop below counts LDS-DMA instructions only, so
-    // everything older (those stores included) has to be acknowledged before it starts
-    if (first && nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);
-    if (PERSIST && ctr) {
-        if (tid == 0) {
-            asm volatile("" : "+v"(ticket));                  // (the value is there: older than everything the wait above lets pend)
-            *next_word = first_free + (int)ticket;
-            if ((int)ticket == chunk - 1) *ctr = 0u;          // the chunk's last ticket (every workgroup draws until it misses): re-arm
-        }
-        WAIT_LGKM0();
-    }
+    // B_lo, B_hi, A_up of K-tile 0 landed (younger: A_dn(0), B, B, A_up(1))
+    if (nload > 4) WAIT_VM2(8, 10); else WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: the wr = 1 group runs one barrier behind
@@ -517,21 +407,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     //  object — tools/asm/mfma_hazard.py, tests/test_mfma_hazard_cpu.py — shows that no VALU instruction of the epilogue writes a
     //  fragment register within 12 slots of the MFMAs that read it, and keeps showing it: the padding is gone)
     stamp(2);
-    // the next tile of a persistent workgroup: its first operands are requested now, behind nothing but this tile's side loads
-    // (the column-sum tail of the epilogue goes through LDS: those launches request at the very end instead)
-    const int m0c = m0, n0c = n0;                          // this tile; m0 / n0 move on with the requests
-    int nextpos = pos + first_free;                        // static walk without a counter
-    if (PERSIST && ctr) nextpos = __builtin_amdgcn_readfirstlane(*(volatile int*)next_word);
-    // (walk: this launch has fewer workgroups than tiles; `tiles_done` bounds the loop whatever the counter returns)
-    const bool more = PERSIST && (int)gridDim.x < nwg && nextpos < chunk && nextpos > pos && ++tiles_done < chunk;
-    const bool early = more && !p.colsum;
-    ln = lane;
-    if constexpr (PERSIST) asm volatile("" : "+v"(ln));
-    if (early) {
-        locate(nextpos * 8 + xme);
-#pragma unroll 1
-        for (int l = 0; l < npro; ++l) { issue(l); __builtin_amdgcn_sched_barrier(0); }   // (one request's addresses at a time: the accumulators are live)
-    }
+    const int m0c = m0, n0c = n0;
     const int g = ln >> 4, rl = ln & 15;
 
     // epilogue, straight from registers (see stage_half_perm): lane (g, c) owns row c of every row tile i and, per column pair
@@ -556,7 +432,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     // for that store's acknowledgement — a ring that refills one slot per unit (loads interleaved with stores) turned the
     // MULAUX epilogue into a chain of write round trips (58 k cycles per 320 x 256 tile).  With batches the wave pays that
     // once per batch boundary: none at all where the side operands of the whole tile fit the registers the dead fragments free.
-    constexpr bool SIDE = OUT_F32 || ACT == 3 || ACT == 4;
+    constexpr bool OUT_F32 = OUT == 1;               // (f32 units are 32 B per lane: smaller side-operand batches)
+    constexpr bool SIDE = OUT != 0 || ACT == 3 || ACT == 4;
     constexpr int NU = 2 * MI;
     constexpr int BU = !SIDE ? NU : (OUT_F32 ? ((ACT == 3 || ACT == 4) ? 4 : (MI == 8 ? 8 : (MI == 6 ? 6 : 5))) : (MI == 10 ? 10 : NU));
     static_assert(NU % BU == 0, "batch size must divide the unit count");
@@ -577,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
                 for (int u = ub; u < ub + BU; ++u) {
                     const int i = u >> 1, jp = u & 1;
                     if (full || (row0 + i * 16 < p.M && colb + jp * 32 < p.N))
-                        epilogue_load_side<ACT, OUT_F32>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
+                        epilogue_load_side<ACT, OUT>(p, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, side[u - ub]);
                 }
             }
 #pragma unroll
@@ -588,15 +465,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-                    epilogue_vec8<ACT, OUT_F32, MODE>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                    epilogue_vec8<ACT, OUT, MODE>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
                                                       side[SIDE ? u - ub : 0]);
                 }
             }
         }
     };
     // (kernel arguments: the tests below are scalar, the whole workgroup takes one path)
-    const bool lean = p.row_group == 0 && (ACT == 5 ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT_F32 ? p.residual != nullptr : p.residual == nullptr);
-    if constexpr (OUT_F32) {
+    const bool lean = p.row_group == 0 && (ACT == 5 ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT != 0 ? p.residual != nullptr : p.residual == nullptr);
+    if constexpr (OUT != 0) {
         if (lean) run_units(std::integral_constant<int, 3>{});
         else run_units(std::integral_constant<int, 0>{});
     } else if constexpr (ACT == 3 || ACT == 4) {      // (the dgrad epilogues always come with bias-gradient column sums in the step)
@@ -607,7 +484,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         else if (lean) run_units(std::integral_constant<int, 2>{});
         else run_units(std::integral_constant<int, 0>{});
     }
-    if (!OUT_F32 && p.colsum) {     // (f32 output + column sums: launch_nt routes that combination to the 128^2 kernel)
+    if (OUT == 0 && p.colsum) {     // (f32 / f16 output + column sums: launch_nt routes that combination to the 128^2 kernel)
         // 16-lane shuffle reduce, then the 8 waves combine through LDS (idle since the main loop's last barrier) so that the
         // workgroup issues 4 atomic wave-instructions for its 256 columns: the chip retires about one atomic wave-instruction per
         // 50 ns and CU whatever its width, and 16 four-lane atomics per wave (128 per tile) cost the MULAUX dgrad 60 us per launch
@@ -624,15 +501,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         const int tc = wave * 64 + ln;              // (= tid, from the epilogue's opaque lane index: nothing hoisted out of the tile loop)
         if (tc < 256 && n0c + tc < p.N) unsafeAtomicAdd(p.colsum + n0c + tc, cs[tc] + cs[256 + tc]);
     }
-    if (more && !early) {
-        __builtin_amdgcn_s_barrier();                      // every wave is done with the column sums' LDS words
-        locate(nextpos * 8 + xme);
-#pragma unroll 1
-        for (int l = 0; l < npro; ++l) { issue(l); __builtin_amdgcn_sched_barrier(0); }   // (one request's addresses at a time: the accumulators are live)
-    }
-    if (!more) break;
-    pos = nextpos;
-  }
     stamp(3);
     if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -1191,75 +1059,48 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
     }
 }
 
+// DCLIP_GEMM256=0: every shape on the 128^2 kernel (the one fallback of this stage); default: the 256- / 320- / 192-row kernel for
+// every shape it tiles — with the towers on four streams, other kernels fill its tail rounds
 bool use_256(const GemmNT& p) {
-    static const int mode = [] { const char* e = getenv("DCLIP_GEMM256"); return e ? atoi(e) : 2; }();
-    if (mode == 0 || p.M < 1024 || p.N < 256) return false;
-    if (mode == 2) return true;     // default: with the towers on four streams, other kernels fill the 256^2 kernel's tail waves
-    if (mode == 3) return !(p.K <= 768 && p.N <= 768);      // experiment: tiny-K / narrow-N GEMMs on the 128^2 kernel
-    // wave quantisation on 256 CUs: the 256^2 kernel runs 1 workgroup / CU, the 128^2 kernel 2 / CU.  Measured intrinsic
-    // advantage of the 256^2 pipeline at equal fill: ~1.2x (tools/diag/gemm_shapes.py).
-    const double t256 = (double)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const double t128 = (double)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const double e256 = t256 / (ceil(t256 / 256.0) * 256.0), e128 = t128 / (ceil(t128 / 512.0) * 512.0);
-    return e256 * 1.2 > e128;
+    static const int mode = [] { const char* e = getenv("DCLIP_GEMM256"); return e ? atoi(e) : 1; }();
+    return mode != 0 && p.M >= 1024 && p.N >= 256;
 }
 
-// rows [0, rows) of the problem stay, the rest is cut off: every row-indexed operand advances
-inline GemmNT tail_rows(GemmNT p, int rows, bool out_f32) {
-    p.A += (int64_t)rows * p.lda;
-    p.C = (char*)p.C + (int64_t)rows * p.ldc * (out_f32 ? 4 : 2);
-    if (p.residual) p.residual += (int64_t)rows * p.ldr;
-    if (p.aux_in) p.aux_in += (int64_t)rows * p.ldc;
-    if (p.aux_out) p.aux_out += (int64_t)rows * p.ldc;
-    p.M -= rows;
-    return p;
+// clock probe (dclip_trace_gemm_clock): slot of the next 256- / 320- / 192-row launch, null when the probe is off
+std::atomic<unsigned long long*> g_clock_buf{nullptr};
+std::atomic<long long> g_clock_cap{0};
+std::atomic<long long> g_clock_count{0};
+inline unsigned long long* next_clock_slot() {
+    unsigned long long* buf = g_clock_buf.load(std::memory_order_acquire);
+    const long long cap = g_clock_cap.load(std::memory_order_relaxed);
+    if (!buf || cap <= 0) return nullptr;
+    return buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % cap);
 }
 
 template <int ACT>
-int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
-    {   // two co-resident 4-wave workgroups per CU (gemm_duo.hip) where the selection asks for them
-        const int rc = launch_nt_duo<ACT>(p, out_f32, st);
-        if (rc != 1) return rc;
-    }
-    if (use_256(p) && !(out_f32 && p.colsum)) {      // (the 256- / 320-row kernels keep column sums only with bf16 output)
+int launch_nt(GemmNT p, int out, hipStream_t st) {
+    // OUT = 2 (f16 output + f16 in-place residual: the frozen teacher's residual stream) exists for the plain epilogue only
+    if constexpr (ACT != 0) { if (out == 2) { dclip_set_error("dclip_gemm_nt: f16 output needs act = DCLIP_ACT_NONE"); return DCLIP_EINVAL; } }
+    const bool out_f32 = out == 1;
+    if (use_256(p) && !(out != 0 && p.colsum)) {      // (the 256- / 320-row kernels keep column sums only with bf16 output)
         int tm = (p.M + 255) / 256;
         const int tn = (p.N + 255) / 256;
-        // Wave quantisation: T tiles on 256 CUs (one 256^2 workgroup each) take ceil(T / 256) rounds.  When the last round would
-        // be mostly empty (300 tiles for every N = 768 GEMM of the image towers: 44 tiles in round 2), the row tiles that fill
-        // whole rounds go to the 256^2 kernel and the remaining rows to the 128^2 kernel (2-3 workgroups per CU), whose short
-        // tiles turn the second round into a fraction of one.
-        // Opt-in (DCLIP_GEMM_SPLITM=1): +2 % step throughput when the towers share one stream, -0.4 % with the default four
-        // streams, where the other towers' kernels already fill the tail round.
-        static const int split_mode = [] { const char* e = getenv("DCLIP_GEMM_SPLITM"); return e ? atoi(e) : 0; }();
-        const int T = tm * tn, R = T / 256, tail = T - 256 * R;
-        GemmNT rest = p;
-        bool has_rest = false;
-        if (split_mode && p.row_group == 0 && R >= 1 && tail > 0 && tail < 160) {
-            const int tm1 = (256 * R) / tn;
-            if (tm1 >= 1 && tm1 < tm) {
-                rest = tail_rows(p, tm1 * 256, out_f32);
-                has_rest = true;
-                p.M = tm1 * 256;
-                tm = tm1;
-            }
-        }
         // tile height: 192, 256 or 320 rows (MI = 6, 8, 10), whichever needs the fewest rounds x cycles per tile on 256 CUs (a tie keeps
         // the 256-row tile, whose loads carry no duplicates); DCLIP_GEMM320=0 keeps 256 rows, =2 forces 320, =6 forces 192
         static const int mode320 = [] { const char* e = getenv("DCLIP_GEMM320"); return e ? atoi(e) : 1; }();
         int mi = 8;
         // (every epilogue variant fits the 160 accumulator registers of the 320-row tile without spilling: tools/diag/regs.py)
-        if (mode320 && !has_rest) {
+        if (mode320) {
             // rounds on 256 CUs x cycles per tile, from the in-kernel stamps (tools/diag/gemm_phases.py): prologue 3.3 k, main
             // loop 2 750 (256 rows) / 3 200 (320 rows) cycles per k-tile — the taller tile does 1.25 x the work in 1.16 x the
             // time; the 192-row tile (M = 12 800 problems, where 320 x 256 tiles leave half the CUs idle at N = 768) is priced at
             // 0.78 x — and an epilogue that scales with the rows (bf16 ~9.5 k, f32 + residual ~40 k when the whole chip stores)
-            static const double tall_bias = [] { const char* e = getenv("DCLIP_GEMM320_BIAS"); return e ? atof(e) : 1.0; }();
-            const double nkt = (double)(p.K / BK), e8 = out_f32 ? 40000.0 : (ACT == 0 || ACT == 4 ? 9500.0 : 14000.0);
+            const double nkt = (double)(p.K / BK), e8 = out_f32 ? 40000.0 : out == 2 ? 24000.0 : (ACT == 0 || ACT == 4 ? 9500.0 : 14000.0);
             auto cost = [&](int rows, double per_kt, double escale) {
                 const int tmx = (p.M + rows - 1) / rows;
                 return (double)((tmx * tn + 255) / 256) * (3300.0 + nkt * per_kt + escale * e8);
             };
-            const double c8 = cost(256, 2750.0, 1.0), c10 = cost(320, 3200.0, 1.25) * tall_bias, c6 = cost(192, 2150.0, 0.75);
+            const double c8 = cost(256, 2750.0, 1.0), c10 = cost(320, 3200.0, 1.25), c6 = cost(192, 2150.0, 0.75);
             if (mode320 == 2) mi = 10;
             else if (mode320 == 6) mi = 6;
             else {
@@ -1269,80 +1110,67 @@ int launch_nt(GemmNT p, bool out_f32, hipStream_t st) {
             tm = (p.M + mi * 32 - 1) / (mi * 32);
         }
         p.tiles_m = tm; p.tiles_n = tn;
-        // persistent launch (opt-in, DCLIP_GEMM_PERSIST=1: 256 workgroups, =N: N rounded down to a multiple of 8): at most one workgroup
-        // per CU, each drawing tiles from its XCD's ticket counter, the next tile's first operands requested under the current epilogue.
-        // Default 0: worth 1-4 % per shape in isolated loops and nothing on the step, while the tile loop costs the kernel 1.5 % in the
-        // step's single-stream probe
-        static const int persist = [] { const char* e = getenv("DCLIP_GEMM_PERSIST"); const int v = e ? atoi(e) : 0; return v == 1 ? 256 : (v & ~7); }();
+        p.clk = next_clock_slot();
         const int ntiles = p.tiles_m * p.tiles_n;
-        const int grid256 = persist > 0 && ntiles > persist && nt256_persistent(ACT, out_f32) ? persist : ntiles;
-        static const int tickets = [] { const char* e = getenv("DCLIP_GEMM_TICKETS"); return e ? atoi(e) : 1; }();
-        const bool walk = grid256 < ntiles;                 // (implies a bf16 store and a persistent-capable epilogue)
-        p.tile_ctr = walk && tickets ? nt256_tile_counters(st) : nullptr;
         // raster group width: minimise the modelled operand bytes from beyond L2 —  A once per group, B once per XCD while a
         // group's B panels (256 x K bf16 each) fit ~2.5 MB of the XCD's 4 MB L2, else once per round of 32 tiles per XCD
         {
-            static const int force_g = [] { const char* e = getenv("DCLIP_GEMM_GROUPN"); return e ? atoi(e) : 0; }();
             const double panel = 512.0 * (double)p.K, a_bytes = 2.0 * (double)p.M * (double)p.K;
             double best = 0.0; int best_g = tn;
             for (int g = 1; g <= tn; ++g) {
                 const int ngroups = (tn + g - 1) / g;
                 const double b_term = (g * panel <= 2.5e6) ? 8.0 * g * panel * (ngroups > 8 ? ngroups / 8.0 : 1.0)
-                                                           : (double)grid256 / 32.0 * g * panel;
+                                                           : (double)ntiles / 32.0 * g * panel;
                 const double cost = a_bytes * ngroups + b_term;
                 if (g == 1 || cost < best * 0.999) { best = cost; best_g = g; }
             }
-            p.group_n = force_g > 0 ? force_g : best_g;
+            p.group_n = best_g;
         }
         if (mi == 10) {
             const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2) + 16;
-            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 10>), dim3(grid256), dim3(512), lds320, st, p);
-            else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10, true>), dim3(grid256), dim3(512), lds320, st, p); }
-            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 10>), dim3(grid256), dim3(512), lds320, st, p);
+            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 10>), dim3(ntiles), dim3(512), lds320, st, p);
+            else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
+            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 10>), dim3(ntiles), dim3(512), lds320, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         if (mi == 6) {
             const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2) + 16;
-            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 6>), dim3(grid256), dim3(512), lds192, st, p);
-            else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6, true>), dim3(grid256), dim3(512), lds192, st, p); }
-            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 6>), dim3(grid256), dim3(512), lds192, st, p);
+            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 6>), dim3(ntiles), dim3(512), lds192, st, p);
+            else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
+            else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 6>), dim3(ntiles), dim3(512), lds192, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         const size_t lds256 = 8 * HT + 16;
-        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, true, 8>), dim3(grid256), dim3(512), lds256, st, p);
-        else if (walk) { if constexpr (nt256_persistent(ACT, false)) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8, true>), dim3(grid256), dim3(512), lds256, st, p); }
-        else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, false, 8>), dim3(grid256), dim3(512), lds256, st, p);
-        if (!has_rest) return dclip_check_launch("dclip_gemm_nt");
-        p = rest;
-        p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 8>), dim3(ntiles), dim3(512), lds256, st, p);
+        else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
+        else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 8>), dim3(ntiles), dim3(512), lds256, st, p);
+        return dclip_check_launch("dclip_gemm_nt");
     }
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NT_LDS;
-    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, true>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<ACT, false>), dim3(grid), dim3(256), lds, st, p);
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, 1>), dim3(grid), dim3(256), lds, st, p);
+    else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt_kernel<0, 2>), dim3(grid), dim3(256), lds, st, p); }
+    else hipLaunchKernelGGL((gemm_nt_kernel<ACT, 0>), dim3(grid), dim3(256), lds, st, p);
     return dclip_check_launch("dclip_gemm_nt");
 }
 
 unsigned long long* g_gemm_stamps = nullptr;
 std::atomic<long long> g_tn_atomic_fallbacks{0};
-unsigned long long* g_clock_buf = nullptr;
-long long g_clock_cap = 0;
-std::atomic<long long> g_clock_count{0};
 
 }  // namespace
 
 extern "C" int dclip_trace_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return 0; }
 extern "C" int64_t dclip_trace_gemm_clock(void* buf, int64_t cap) {
     const long long n = g_clock_count.exchange(0, std::memory_order_relaxed);
-    g_clock_buf = (unsigned long long*)buf;
-    g_clock_cap = buf ? (long long)cap : 0;
+    g_clock_cap.store(buf ? (long long)cap : 0, std::memory_order_relaxed);
+    g_clock_buf.store((unsigned long long*)buf, std::memory_order_release);
     return (int64_t)n;
 }
 extern "C" int64_t dclip_gemm_tn_atomic_fallbacks(void) { return (int64_t)g_tn_atomic_fallbacks.load(std::memory_order_relaxed); }
 
 extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                              int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
-                             const void* aux_in, void* aux_out, const float* residual, int64_t ldr, int out_f32,
+                             const void* aux_in, void* aux_out, const void* residual, int64_t ldr, int out_dtype,
                              int64_t row_group, const float* rowadd, float* colsum_acc, void* stream) {
     DCLIP_REQUIRE(A && B && C, "dclip_gemm_nt: null operand");
     DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "dclip_gemm_nt: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
@@ -1350,41 +1178,44 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     DCLIP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
                   "dclip_gemm_nt: operand rows must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
     DCLIP_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0, "dclip_gemm_nt: N and ldc must be multiples of 8 and C 16-byte aligned (N=%ld ldc=%ld)", (long)N, (long)ldc);
-    DCLIP_REQUIRE(!residual || (ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "dclip_gemm_nt: residual rows must be 16-byte aligned");
+    DCLIP_REQUIRE(out_dtype >= 0 && out_dtype <= 2, "dclip_gemm_nt: bad output dtype %d (0 bf16, 1 f32, 2 f16)", out_dtype);
+    DCLIP_REQUIRE(!residual || (ldr % (out_dtype == 2 ? 8 : 4) == 0 && ((uintptr_t)residual % 16) == 0), "dclip_gemm_nt: residual rows must be 16-byte aligned");
     DCLIP_REQUIRE(act >= 0 && act <= 5, "dclip_gemm_nt: bad activation code %d", act);
+    DCLIP_REQUIRE(out_dtype != 2 || act == 0, "dclip_gemm_nt: f16 output needs act = DCLIP_ACT_NONE");
     DCLIP_REQUIRE((act != DCLIP_ACT_DGELU && act != DCLIP_ACT_MULAUX) || aux_in, "dclip_gemm_nt: DGELU / MULAUX need aux_in");
+    DCLIP_REQUIRE(!aux_in || ((uintptr_t)aux_in % 16) == 0, "dclip_gemm_nt: aux_in must be 16-byte aligned");
+    DCLIP_REQUIRE(!aux_out || ((uintptr_t)aux_out % 16) == 0, "dclip_gemm_nt: aux_out must be 16-byte aligned");
     DCLIP_REQUIRE(row_group == 0 || rowadd, "dclip_gemm_nt: row_group needs rowadd");
     DCLIP_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "dclip_gemm_nt: dimension overflow");
     GemmNT p;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha; p.bias = bias;
-    p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.residual = residual; p.ldr = ldr;
+    p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.ldr = ldr;
     p.row_group = (int)row_group; p.rowadd = rowadd; p.colsum = colsum_acc;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
-    p.duo_prio = 0;
-    p.tile_ctr = nullptr;
     p.clk = nullptr;
-    if (g_clock_buf && g_clock_cap > 0) p.clk = g_clock_buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % g_clock_cap);
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes of the call: both operands once, the output once, plus what the fused epilogue consumes / produces — the f32 residual
     // it adds (read), the saved pre-activation / derivative it multiplies by (aux_in) or stores (aux_out); round 3 counted operands + output only
+    const int out_f32 = out_dtype == 1;
+    const double aux_b = (act == DCLIP_ACT_MULAUX || act == DCLIP_ACT_GELU_SAVE) ? 1.0 : 2.0;      // the saved gelu' is one byte per element
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
-                  2.0 * ((double)M * K + (double)N * K) + ((out_f32 ? 4.0 : 2.0) + (residual ? 4.0 : 0.0) + (aux_in ? 2.0 : 0.0) + (aux_out ? 2.0 : 0.0)) * (double)M * N,
+                  2.0 * ((double)M * K + (double)N * K) + ((out_f32 ? 4.0 : 2.0) + (residual ? (out_dtype == 2 ? 2.0 : 4.0) : 0.0) + (aux_in ? aux_b : 0.0) + (aux_out ? aux_b : 0.0)) * (double)M * N,
                   stream, (int)M, (int)N, (int)K,
-                  act + 8 * (out_f32 != 0) + 16 * (residual != nullptr) + 32 * (colsum_acc != nullptr));
+                  act + 8 * (out_f32 != 0) + 16 * (residual != nullptr) + 32 * (colsum_acc != nullptr) + 64 * (out_dtype == 2));
     switch (act) {
-        case 0: return launch_nt<0>(p, out_f32 != 0, st);
-        case 1: return launch_nt<1>(p, out_f32 != 0, st);
-        case 2: return launch_nt<2>(p, out_f32 != 0, st);
-        case 3: return launch_nt<3>(p, out_f32 != 0, st);
-        case 4: return launch_nt<4>(p, out_f32 != 0, st);
-        default: return launch_nt<5>(p, out_f32 != 0, st);
+        case 0: return launch_nt<0>(p, out_dtype, st);
+        case 1: return launch_nt<1>(p, out_dtype, st);
+        case 2: return launch_nt<2>(p, out_dtype, st);
+        case 3: return launch_nt<3>(p, out_dtype, st);
+        case 4: return launch_nt<4>(p, out_dtype, st);
+        default: return launch_nt<5>(p, out_dtype, st);
     }
 }
 
-// room for the partial tiles of the largest 256^2 wgrad launch (~one workgroup per CU, DCLIP_TN256_BLOCKS, plus rounding)
+// room for the partial tiles of the largest 256^2 wgrad launch (~one workgroup per CU, plus rounding)
 extern "C" size_t dclip_gemm_tn_workspace_bytes(void) { return (size_t)384 * 65536 * sizeof(float); }
 
 extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t ldo,
@@ -1404,17 +1235,13 @@ extern "C" int dclip_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     p.chunk = chunk;
     p.splits = (int)((M + chunk - 1) / chunk);
     const int grid = p.tiles_p * p.tiles_q * p.splits;
-    static const int tn_mode = [] { const char* e = getenv("DCLIP_TN_GLDS"); return e ? atoi(e) : 1; }();
-    const bool fast = tn_mode != 0 && M % TC == 0 && P >= 8 && Q >= 8;
+    const bool fast = M % TC == 0 && P >= 8 && Q >= 8;
     // 256^2 pipeline for the large outputs: one workgroup per CU, every workgroup a long slice of the token axis
-    static const int tn256_mode = [] { const char* e = getenv("DCLIP_TN256"); return e ? atoi(e) : 1; }();
-    static const int tn256_min_tiles = [] { const char* e = getenv("DCLIP_TN256_MIN_TILES"); return e ? atoi(e) : 16; }();
-    if (tn256_mode != 0 && fast && P % 256 == 0 && Q % 256 == 0 && (P / 256) * (Q / 256) >= tn256_min_tiles && M >= 4096) {
+    if (fast && P % 256 == 0 && Q % 256 == 0 && (P / 256) * (Q / 256) >= 16 && M >= 4096) {
         GemmTN q = p;
         q.tiles_p = (int)(P / 256); q.tiles_q = (int)(Q / 256);
         const int tiles = q.tiles_p * q.tiles_q;
-        static const int tn256_blocks = [] { const char* e = getenv("DCLIP_TN256_BLOCKS"); return e ? atoi(e) : 256; }();
-        int s = (tn256_blocks + tiles / 2) / tiles;             // ~ one workgroup per CU
+        int s = (256 + tiles / 2) / tiles;                      // ~ one workgroup per CU
         if (s < 1) s = 1;
         int ch = (int)((M + s - 1) / s);
         ch = ((ch + TC - 1) / TC) * TC;

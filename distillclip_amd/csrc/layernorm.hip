@@ -9,30 +9,30 @@ namespace {
 
 constexpr int LN_MAXV = 4;   // float4 chunks per lane: D <= 64 * 4 * 4 = 1024
 
-// ADD: the row normalised is x[row] + delta[row] (delta bf16: the output of the linear that feeds the residual stream), and that sum
-// is also written to xsum[row] — the residual add of `x = x + mlp(ln_2(x))` done here instead of in the GEMM's epilogue (x and xsum
-// are not restrict-qualified: they are the same buffer in the inference towers)
-template <int NV, bool OUT_F32, bool ADD>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, int64_t ldx, const int* __restrict__ ridx,
+// X_F16: the rows are fp16 — the frozen teacher's residual stream, stored in the 16-bit type the reference's `precision: 16` autocast
+// keeps it in (_common.py:14-20: the custom LayerNorm computes in fp32 and returns the input's type); statistics stay f32
+template <int NV, int OUT, bool X_F16>      // OUT: 0 bf16, 1 f32, 2 f16
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, int64_t ldx, const int* __restrict__ ridx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      void* __restrict__ y, int64_t ldy, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int D, float eps,
-                                                     const bf16_t* __restrict__ delta, int64_t ldd, float* xsum, int64_t ldxs) {
+                                                     float* __restrict__ rstd, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t src = ridx ? ridx[row] : row;
-    const float* xr = x + src * ldx;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = c < D ? *(const float4*)(xr + c) : float4{0.f, 0.f, 0.f, 0.f};
-        if (ADD && c < D) {
-            const bf16x4 d = *(const bf16x4*)(delta + src * ldd + c);
-            v[i].x += bf2f(d[0]); v[i].y += bf2f(d[1]); v[i].z += bf2f(d[2]); v[i].w += bf2f(d[3]);
-            *(float4*)(xsum + src * ldxs + c) = v[i];
+        v[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            if (X_F16) {
+                const f16x4 h = *(const f16x4*)((const _Float16*)x + src * ldx + c);
+                v[i] = float4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            } else {
+                v[i] = *(const float4*)((const float*)x + src * ldx + c);
+            }
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, int64_t ldx
             const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
             const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
             const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
-            if (OUT_F32) {
+            if (OUT == 1) {
                 *(float4*)((float*)y + (int64_t)row * ldy + c) = float4{o0, o1, o2, o3};
+            } else if (OUT == 2) {
+                *(f16x4*)((_Float16*)y + (int64_t)row * ldy + c) = f16x4{(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
             } else {
                 bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
                 *(bf16x4*)((bf16_t*)y + (int64_t)row * ldy + c) = o;
@@ -208,38 +210,34 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
         default: { constexpr int NV = 4; __VA_ARGS__; break; } \
     }
 
+static int ln_fwd_launch(const void* x, int x_f16, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta, void* y,
+                         int64_t ldy, int out, float* mean, float* rstd, int64_t M, int64_t D, float eps, void* stream, const char* who) {
+    DCLIP_REQUIRE(x && gamma && beta && y, "%s: null operand", who);
+    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "%s: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", who, (long)D);
+    DCLIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % (x_f16 ? 8 : 16)) == 0, "%s: row strides must be multiples of 4, rows 8- (fp16) / 16-byte aligned", who);
+    DCLIP_REQUIRE(out >= 0 && out <= 2 && (out != 2 || x_f16), "%s: output dtype 0 bf16 / 1 f32 (/ 2 f16 with f16 input)", who);
+    const int nv = (int)((D + 255) / 256);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    TraceScope tr(DCLIP_TRACE_LAYERNORM, 8.0 * (double)M * D, (double)M * D * ((x_f16 ? 2.0 : 4.0) + (out == 1 ? 4.0 : 2.0)), stream);
+#define LN_GO(OUTV, XH) hipLaunchKernelGGL((ln_fwd_kernel<NV, OUTV, XH>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps)
+    LN_DISPATCH(nv,
+        if (x_f16) { if (out == 2) LN_GO(2, true); else if (out == 1) LN_GO(1, true); else LN_GO(0, true); }
+        else { if (out == 1) LN_GO(1, false); else LN_GO(0, false); });
+#undef LN_GO
+    return dclip_check_launch(who);
+}
+
 extern "C" int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma,
                                    const float* beta, void* y, int64_t ldy, int out_f32, float* mean, float* rstd,
                                    int64_t M, int64_t D, float eps, void* stream) {
-    DCLIP_REQUIRE(x && gamma && beta && y, "dclip_layernorm_fwd: null operand");
-    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_fwd: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
-    DCLIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "dclip_layernorm_fwd: row strides must be multiples of 4");
-    const int nv = (int)((D + 255) / 256);
-    const dim3 grid((unsigned)((M + 3) / 4));
-    hipStream_t st = (hipStream_t)stream;
-    TraceScope tr(DCLIP_TRACE_LAYERNORM, 8.0 * (double)M * D, (double)M * D * (4.0 + (out_f32 ? 4.0 : 2.0)), stream);
-    LN_DISPATCH(nv,
-        if (out_f32) hipLaunchKernelGGL((ln_fwd_kernel<NV, true, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps, nullptr, 0, nullptr, 0);
-        else hipLaunchKernelGGL((ln_fwd_kernel<NV, false, false>), grid, dim3(256), 0, st, x, ldx, row_index, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps, nullptr, 0, nullptr, 0));
-    return dclip_check_launch("dclip_layernorm_fwd");
+    return ln_fwd_launch(x, 0, ldx, row_index, gamma, beta, y, ldy, out_f32 ? 1 : 0, mean, rstd, M, D, eps, stream, "dclip_layernorm_fwd");
 }
 
-extern "C" int dclip_layernorm_fwd_add(const float* x, int64_t ldx, const void* delta, int64_t ldd, float* xsum, int64_t ldxs,
-                                       const float* gamma, const float* beta, void* y, int64_t ldy, float* mean, float* rstd,
+extern "C" int dclip_layernorm_fwd_f16(const void* x, int64_t ldx, const int32_t* row_index, const float* gamma,
+                                       const float* beta, void* y, int64_t ldy, int out_dtype, float* mean, float* rstd,
                                        int64_t M, int64_t D, float eps, void* stream) {
-    DCLIP_REQUIRE(x && delta && xsum && gamma && beta && y, "dclip_layernorm_fwd_add: null operand");
-    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_layernorm_fwd_add: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
-    DCLIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldd % 4 == 0 && ldxs % 4 == 0 && ((uintptr_t)delta % 8) == 0 && ((uintptr_t)xsum % 16) == 0,
-                  "dclip_layernorm_fwd_add: row strides must be multiples of 4, delta 8-byte and xsum 16-byte aligned");
-    const int nv = (int)((D + 255) / 256);
-    const dim3 grid((unsigned)((M + 3) / 4));
-    hipStream_t st = (hipStream_t)stream;
-    // algorithmic bytes: read x (4) + delta (2), write the sum (4) + the normalised bf16 rows (2)
-    TraceScope tr(DCLIP_TRACE_LAYERNORM, 9.0 * (double)M * D, (double)M * D * 12.0, stream);
-    LN_DISPATCH(nv,
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, false, true>), grid, dim3(256), 0, st, x, ldx, nullptr, gamma, beta, y, ldy, mean, rstd, (int)M, (int)D, eps,
-                           (const bf16_t*)delta, ldd, xsum, ldxs));
-    return dclip_check_launch("dclip_layernorm_fwd_add");
+    return ln_fwd_launch(x, 1, ldx, row_index, gamma, beta, y, ldy, out_dtype, mean, rstd, M, D, eps, stream, "dclip_layernorm_fwd_f16");
 }
 
 extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx,
@@ -252,9 +250,7 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
     // persistent grid of 8-wave blocks, one per CU (the kernel's registers allow 2 waves per SIMD): every block ends with 3 x D
     // float atomics onto the same 3 D / 32 cache lines, so fewer, fatter blocks are cheaper — as long as every CU has one
     int blocks = (int)((M + 7) / 8);
-    static const int force_blocks = [] { const char* e = getenv("DCLIP_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
-    const int want = force_blocks > 0 ? force_blocks : 256;
-    if (blocks > want) blocks = want;
+    if (blocks > 256) blocks = 256;
     // algorithmic bytes: read dy (2 or 4), x (4), dx_acc (4) ; write dx_acc (4) + optional bf16 copy (2)
     TraceScope tr(DCLIP_TRACE_LN_BWD, 12.0 * (double)M * D, (double)M * D * ((dy_f32 ? 4.0 : 2.0) + 12.0 + (dx_bf16 ? 2.0 : 0.0)), stream, (int)M, (int)D, 0, 0);
     hipStream_t st = (hipStream_t)stream;

@@ -46,11 +46,6 @@ struct LossArgs {
     int zs;                                   // column slices of the stripe kernels (blockIdx.z): fills the chip at B = 512
     float* dsh[2];                            // d loss / d normalised student embedding [zs][B,E] (partials per slice)
     float* scal;                              // [NREP][SCSTRIDE] atomically accumulated (replicated, see NREP)
-    unsigned* arrive;                         // arrival counters, zeroed with `scal` by the one fill of a call: [0] workgroups of the
-                                              // call's last kernel, [1 + dir * ceil(Bl / 16) + stripe] column slices of a stripe
-    int final_in_rows;                        // no cross-modal term: loss_rows_kernel is the last kernel
-    int fuse;                                 // 1: the follow-up work (normalisation backward, the 16 scalars) is done by last-arriving
-                                              // workgroups of the call's last kernel instead of by launches of their own (see last_arriver)
     float* out;                               // [16] user-visible scalars
     int B, E;                                 // B: number of columns = rows of the (gathered) inputs
     int r0, Bl;                               // the rows this call owns: [r0, r0 + Bl) (whole matrix: 0, B).  Row-block mode:
@@ -61,24 +56,6 @@ struct LossArgs {
 __device__ __forceinline__ float* scal_slot(const LossArgs& a) {
     const unsigned r = (blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z + 7u * (threadIdx.x >> 6)) % NREP;
     return a.scal + r * SCSTRIDE;
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// "last arriver" hand-over inside ONE launch (no spinning, nobody waits): every workgroup publishes what it wrote
-// (agent-scope release fence), then adds one to a counter; the workgroup that draws the last ticket knows that all the
-// others' results are visible after its own acquire fence and does the follow-up work that used to be a separate launch
-// (round 3: loss_finalize_kernel after loss_stripe_b_kernel, loss_total_kernel after everything).  The follow-up reads in a fixed
-// order, so the results stay run-to-run identical whichever workgroup happens to be last.
-// -------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool last_arriver(unsigned* counter, unsigned expected) {
-    __shared__ unsigned ticket;
-    __threadfence();                                        // release: this thread's stores and atomics, agent scope
-    __syncthreads();                                        // ... of every thread of the workgroup
-    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const bool last = ticket == expected - 1;
-    if (last) __threadfence();                              // acquire
-    return last;
 }
 
 __device__ void loss_write_total(const LossArgs& a);
@@ -190,8 +167,6 @@ __device__ __forceinline__ void loss_rows_body(const LossArgs& a) {
 template <int NV>
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     loss_rows_body<NV>(a);
-    // without cross-modal terms this is the call's only kernel: whoever finishes last writes the 16 scalars
-    if (a.final_in_rows && a.fuse && last_arriver(a.arrive, gridDim.x)) loss_write_total(a);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -415,16 +390,6 @@ __global__ __launch_bounds__(256) void loss_stripe_b_kernel(LossArgs a) {
             if (row < iend) G[(int64_t)(row - a.r0) * E + e0 + (lane & 15)] = acc[q];
         }
     }
-    if (!a.fuse) return;
-    // the stripe's last column slice adds the slices' partial rows and applies the normalisation backward
-    const int nstripe = gridDim.x;
-    if (last_arriver(a.arrive + 1 + dir * nstripe + blockIdx.x, (unsigned)a.zs)) {
-#pragma unroll 1
-        for (int r = wave; r < 16; r += 4)
-            if (i0 + r < iend) loss_finalize_row(a, dir, i0 - a.r0 + r, lane);
-    }
-    // ... and the call's last workgroup the scalars
-    if (last_arriver(a.arrive, gridDim.x * gridDim.y * gridDim.z)) loss_write_total(a);
 }
 
 // pass-A-only call of the row-block mode: the owned rows' statistics, slices added in order, for the caller's all-gather
@@ -437,7 +402,7 @@ __global__ void loss_stats_out_kernel(LossArgs a) {
 }
 
 // out[0] total ; [1..4] image l1,cos,kl,ce ; [5..8] text ; [9..12] cos_diff, hard_label, soft_label, logits_mse (raw)
-// (run by every thread of the call's last-arriving workgroup)
+// (run by every thread of one workgroup: the extra workgroup of loss_finalize_kernel, or loss_total_kernel)
 __device__ void loss_write_total(const LossArgs& a) {
     __shared__ float tot[NSC];
     if (threadIdx.x < NSC) {
@@ -488,14 +453,13 @@ __global__ __launch_bounds__(64) void loss_total_kernel(LossArgs a) { loss_write
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // arrival counters behind the scalar accumulators: one for the call, one per (direction, 16-row stripe)
-inline size_t arrive_bytes(int64_t rows) { return align_up((size_t)(1 + 2 * ((rows + 15) / 16)) * sizeof(unsigned)); }
 
 }  // namespace
 
 extern "C" size_t dclip_distill_loss_workspace(int64_t B, int64_t E) {
     const size_t be = align_up((size_t)B * E * sizeof(float));
     const size_t zs = 8;                                     // upper bound of loss_slices() for any row block
-    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up((size_t)NREP * SCSTRIDE * 4) + arrive_bytes(B);
+    return (4 + 2 * zs) * be + align_up((size_t)2 * B * 4) + align_up(zs * 6 * B * 4) + align_up((size_t)NREP * SCSTRIDE * 4);
 }
 
 namespace {
@@ -537,21 +501,14 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
     for (int i = 0; i < 2; ++i) { a.dsh[i] = (float*)w; w += (size_t)a.zs * be; }
     a.inv[0] = (float*)w; a.inv[1] = a.inv[0] + rows; w += align_up((size_t)2 * B * 4);
     a.stats = (float*)w; w += align_up((size_t)a.zs * 6 * B * 4);
-    a.scal = (float*)w; w += align_up((size_t)NREP * SCSTRIDE * 4);
-    a.arrive = (unsigned*)w;
+    a.scal = (float*)w;
     const bool cross = a.c.two_tower && (a.c.w_cd != 0.f || a.c.w_hl != 0.f || a.c.w_sl != 0.f || a.c.w_mse != 0.f);
-    a.final_in_rows = cross ? 0 : 1;
-    // DCLIP_LOSS_FUSE=1: three kernels (rows, stripe A, stripe B) with the follow-up work done by last-arriving workgroups.  Measured
-    // slower than the default four (rows, A, B, finalize + scalars) on the 8-XCD part: 0.176 against 0.136 ms per call at B = 512 — the
-    // agent-scope release / acquire fences of 256 workgroups write back and invalidate their XCD's L2
-    static const int fuse = [] { const char* e = getenv("DCLIP_LOSS_FUSE"); return e ? atoi(e) : 0; }();
-    a.fuse = fuse;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic HBM bytes: read 4*B*E*4 + write 2*rows*E*4 ; the logits contribute none
     TraceScope tr(DCLIP_TRACE_LOSS, 0.0, (a.c.two_tower ? 2.0 : 1.0) * (2.0 * (double)B + (double)rows) * E * 4.0, stream);
-    // launches of a call: this fill (accumulators + arrival counters, adjacent), rows, and with cross-modal terms stripe A, stripe B
+    // launches of a call: this fill (the replicated scalar accumulators), rows, and with cross-modal terms stripe A, stripe B
     // and the normalisation backward, whose extra workgroup writes the 16 scalars (round 3: a fifth launch)
-    if (hipMemsetAsync(a.scal, 0, align_up((size_t)NREP * SCSTRIDE * sizeof(float)) + arrive_bytes(rows), st) != hipSuccess) {
+    if (hipMemsetAsync(a.scal, 0, align_up((size_t)NREP * SCSTRIDE * sizeof(float)), st) != hipSuccess) {
         dclip_set_error("%s: memset failed", who);
         return DCLIP_ELAUNCH;
     }
@@ -573,8 +530,8 @@ int run_distill_loss(const float* s_img, const float* t_img, const float* s_txt,
         const size_t lds = (size_t)16 * (((((B + 15) / 16) + a.zs - 1) / a.zs) * 16 + 4) * sizeof(float);
         DCLIP_REQUIRE(lds <= 160 * 1024, "%s: stripe does not fit LDS", who);
         hipLaunchKernelGGL(loss_stripe_b_kernel, grid, dim3(256), lds, st, a);
-        if (!a.fuse) hipLaunchKernelGGL(loss_finalize_kernel, dim3((unsigned)((rows + 3) / 4) + 1), dim3(256), 0, st, a);
-    } else if (!a.fuse) {
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3((unsigned)((rows + 3) / 4) + 1), dim3(256), 0, st, a);
+    } else {
         hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a);
     }
     return dclip_check_launch(who);

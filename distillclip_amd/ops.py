@@ -5,6 +5,9 @@ import torch
 from ._lib import lib
 
 ACT = {'none': 0, None: 0, 'quickgelu': 1, 'gelu': 2, 'dgelu': 3, 'mulaux': 4, 'gelu_save': 5}
+OUT_DTYPE = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}      # DCLIP_OUT_*
+# 8-bit fixed-point code of the saved gelu' (include/dclip.h: DCLIP_ACT_GELU_SAVE / DCLIP_ACT_MULAUX): value = DG_LO + q * DG_STEP
+DG_LO, DG_STEP = -0.13, 1.26 / 255.0
 
 
 def _p(t):
@@ -23,7 +26,9 @@ def _chk(*ts):
 
 def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=None, out=None, out_dtype=torch.bfloat16,
             alpha=1.0, row_group=0, rowadd=None, out_rows=None, colsum=None):
-    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K]^T); see include/dclip.h:dclip_gemm_nt."""
+    """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K]^T); see include/dclip.h:dclip_gemm_nt.
+    act='gelu_save' writes / act='mulaux' reads the 8-bit gelu' (uint8 [M,N]); out_dtype float16 = the teacher's fp16 residual stream
+    (residual then float16 too, act none)."""
     _chk(a, b, bias, aux_in, aux_out, residual, out, rowadd)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -34,9 +39,15 @@ def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=No
         out = torch.empty((rows, N), dtype=out_dtype, device=a.device)
     assert out.stride(1) == 1
     ldr = residual.stride(0) if residual is not None else 0
+    if act == 'gelu_save' and aux_out is not None:
+        assert aux_out.dtype == torch.uint8 and aux_out.stride(0) == out.stride(0)
+    if act == 'mulaux':
+        assert aux_in.dtype == torch.uint8 and aux_in.stride(0) == out.stride(0)
+    if residual is not None:
+        assert residual.dtype == (torch.float16 if out.dtype == torch.float16 else torch.float32)
     lib().dclip_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
                         _p(bias), ACT[act], _p(aux_in), _p(aux_out), _p(residual), ldr,
-                        1 if out.dtype == torch.float32 else 0, row_group, _p(rowadd), _p(colsum), _stream())
+                        OUT_DTYPE[out.dtype], row_group, _p(rowadd), _p(colsum), _stream())
     return out
 
 
@@ -74,32 +85,17 @@ def colsum_acc(x, db):
 
 
 def layernorm_fwd(x, gamma, beta, *, row_index=None, out_dtype=torch.bfloat16, eps=1e-5, save_stats=True):
+    """x f32, or f16 (the frozen teacher's residual stream: dclip_layernorm_fwd_f16, which can also return f16)"""
     _chk(x, gamma, beta, row_index)
-    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    assert x.dtype in (torch.float32, torch.float16) and x.dim() == 2 and x.stride(1) == 1
     M = row_index.numel() if row_index is not None else x.shape[0]
     D = x.shape[1]
     y = torch.empty((M, D), dtype=out_dtype, device=x.device)
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
-    lib().dclip_layernorm_fwd(_p(x), x.stride(0), _p(row_index), _p(gamma), _p(beta), _p(y), D,
-                              1 if out_dtype == torch.float32 else 0, _p(mean), _p(rstd), M, D, eps, _stream())
+    fn = lib().dclip_layernorm_fwd_f16 if x.dtype == torch.float16 else lib().dclip_layernorm_fwd
+    fn(_p(x), x.stride(0), _p(row_index), _p(gamma), _p(beta), _p(y), D, OUT_DTYPE[out_dtype], _p(mean), _p(rstd), M, D, eps, _stream())
     return y, mean, rstd
-
-
-def layernorm_fwd_add(x, delta, gamma, beta, *, xsum=None, eps=1e-5, save_stats=True):
-    """xsum = x + delta (bf16 delta: a linear's output; xsum may be x itself), y = LN(xsum) in bf16: the residual add of
-    `x = x + mlp(ln_2(x))` (reference _common.py:125, weight_share_model.py:184) done by the LayerNorm that reads the sum next"""
-    _chk(x, delta, gamma, beta, xsum)
-    assert x.dtype == torch.float32 and delta.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and delta.stride(1) == 1
-    M, D = x.shape
-    if xsum is None:
-        xsum = torch.empty_like(x)
-    y = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
-    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
-    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
-    lib().dclip_layernorm_fwd_add(_p(x), x.stride(0), _p(delta), delta.stride(0), _p(xsum), xsum.stride(0), _p(gamma), _p(beta),
-                                  _p(y), D, _p(mean), _p(rstd), M, D, eps, _stream())
-    return y, xsum, mean, rstd
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_acc, *, row_index=None, dx_bf16=None, dgamma=None, dbeta=None, colsum=None):
@@ -227,22 +223,6 @@ def feature_mse(s, t, coef=1.0):
     ds = torch.zeros_like(s)
     lib().dclip_feature_mse(_p(s), _p(t), s.numel(), float(coef), _p(val), _p(ds), _stream())
     return val[0], ds
-
-
-def attn_student_fwd(qkv, B, N, H, hd, wl, ww, scale, save=True):
-    """fused student attention forward: -> (ctx [B*N, H*hd] bf16, S, P, R [B,H,N,Np] bf16); see include/dclip.h"""
-    _chk(qkv, wl, ww)
-    Np = (N + 7) // 8 * 8
-    D = H * hd
-    assert qkv.dtype == torch.bfloat16 and qkv.shape == (B * N, 3 * D) and qkv.stride(1) == 1
-    if not lib().dclip_attn_student_fwd_supported(H, N, hd):
-        raise ValueError(f'attn_student_fwd: no fused instantiation for H={H} N={N} hd={hd}')
-    mk = lambda: torch.zeros((B, H, N, Np), dtype=torch.bfloat16, device=qkv.device)
-    S, P, R = (mk() if save else None), (mk() if save else None), mk()
-    ctx = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
-    lib().dclip_attn_student_fwd(_p(qkv), qkv.stride(0), _p(wl), _p(ww), _p(S), _p(P), _p(R), _p(ctx), D, B, H, N, Np, hd, float(scale),
-                                 _stream())
-    return ctx, S, P, R
 
 
 def attn_mix_fwd(qkv, B, N, H, hd, wl, ww, scale):

@@ -53,10 +53,38 @@ class FusedAdamW:
                           self.betas[1], self.eps, self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
 
     def zero_grad(self, set_to_none=False):
+        from .model.component._tower import autograd_params_mode
         for tw in self.towers:
+            if tw.flat is not None and autograd_params_mode(tw):
+                # the gradients belong to autograd (AccumulateGrad / a DDP reducer): drop them, as torch's zero_grad(set_to_none) does
+                for p in tw._params():
+                    if p is not None and p.requires_grad:
+                        p.grad = None
             if tw.flat_grad is not None and not getattr(tw, '_grad_clean', False):
                 self.join()
                 tw.flat_grad.zero_()
+
+    @staticmethod
+    def _pack_autograd_grads(tw):
+        """DCLIP_DP_MODE=off / tower.autograd_params: the backward handed the parameter gradients to autograd, so p.grad are autograd's own
+        tensors (or a DistributedDataParallel reducer's bucket views) and tower.flat_grad, which the kernel below reads, was never
+        written.  Copy them into the flat buffer (one multi-tensor copy); a trainable parameter without a gradient counts as zero."""
+        dst, src = [], []
+        live = [p for p in tw._params() if p is not None]
+        for p, off in zip(live, tw._offsets):
+            if not p.requires_grad:
+                continue
+            view = tw.flat_grad[off:off + p.numel()]
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != view.data_ptr():
+                if g.dtype != torch.float32 or g.device != view.device:
+                    raise RuntimeError('FusedAdamW: parameter gradients must be f32 tensors on the tower\'s device')
+                dst.append(view)
+                src.append(g.reshape(-1))
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _ranges_cover_everything(self, tw):
         r = self._ranges(tw)
@@ -128,6 +156,7 @@ class FusedAdamW:
         dependency (backward -> exchange -> update -> next forward of that tower) and the next step's frozen teacher towers
         may start while the last gradient exchange and update are still running; join() orders the current stream after them
         (zero_grad() and state_dict() call it)."""
+        from .model.component._tower import autograd_params_mode
         self.step_count += 1
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
         joined = []
@@ -140,7 +169,9 @@ class FusedAdamW:
                     joined.append(s)
                 continue
             m, v = self._moments(tw)
-            stream = tw.bwd_stream if (overlap and getattr(tw, 'bwd_stream', None) is not None) else main
+            through_autograd = autograd_params_mode(tw)
+            # (gradients that went through autograd may have been written by anybody's stream — a DDP reducer's —: take them on `main`)
+            stream = tw.bwd_stream if (overlap and not through_autograd and getattr(tw, 'bwd_stream', None) is not None) else main
             if stream != main:
                 stream.wait_stream(main)                     # whatever the caller enqueued before step() (e.g. zero_grad of others)
             if getattr(tw, 'grads_ready', None) is not None:
@@ -148,6 +179,8 @@ class FusedAdamW:
                 tw.grads_ready = None
             with torch.cuda.stream(stream):
                 st = stream.cuda_stream
+                if through_autograd:
+                    self._pack_autograd_grads(tw)
                 for b, e in self._ranges(tw):
                     self._adamw(tw.flat[b:e], tw.flat_grad[b:e], m[b:e], v[b:e], zero_grad, st)
                 tw.wcache_dirty = True

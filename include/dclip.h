@@ -5,16 +5,20 @@
  * The boundary this library replaces is therefore the implicit ATen kernel sequence behind the reference's
  * nn.Module calls.  Each entry point cites the reference call site (file:line under the reference root) whose
  * arithmetic it implements.  All pointers are raw device pointers; `stream` is a hipStream_t passed as void*.
- * No synchronisation inside any entry point and no allocation, with one exception: the opt-in persistent launches of dclip_gemm_nt (DCLIP_GEMM_PERSIST) draw
- * their tiles from eight 4-byte ticket counters per stream (1 KiB, hipMalloc'ed and zeroed on that stream the first time a stream
- * issues such a launch, kept for the life of the process; every launch leaves them at zero).  No other global mutable state on the
- * compute path: the remaining process-global state is the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback
- * counter) and the tuning knobs read from DCLIP_* environment variables, which are latched once on first use and constant
- * afterwards.  Every function returns
+ * No synchronisation inside any entry point, no allocation, no global mutable state on the compute path: the process-global state is
+ * the opt-in profiling hooks (dclip_trace_*: launch trace, GEMM stamps / clock stamps; the wgrad fallback counter) and a handful of
+ * tuning knobs read from DCLIP_* environment variables, latched once on first use and constant
+ * afterwards.  A dclip_encoder handle additionally remembers which workspace its last training forward
+ * prepared for a backward (dclip_encoder_backward below).  Every function returns
  * 0 on success, DCLIP_EINVAL (-1) for a bad argument, DCLIP_ELAUNCH (-2) for a HIP launch failure, and
  * dclip_last_error_string() (thread-local) explains the last failure.
  *
- * dtypes: "bf16" = bfloat16 storage (MFMA operands), "f32" = float.  Row-major everywhere.
+ * dtypes: "bf16" = bfloat16 storage (MFMA operands), "f32" = float, "f16" = IEEE half (the frozen teacher's residual stream, the
+ * 16-bit type the reference's `precision: 16` autocast keeps it in).  Row-major everywhere.
+ *
+ * Load order: the library links the HIP runtime (libamdhip64) the usual way.  A process that also loads PyTorch-ROCm must import torch
+ * BEFORE this library is mapped, so that both resolve to the one HIP runtime torch ships (two runtimes in one process do not see each
+ * other's device state: "no ROCm-capable device is detected").  dclip_runtime_check() reports that condition in words.
  */
 #ifndef DCLIP_H
 #define DCLIP_H
@@ -29,6 +33,9 @@ extern "C" {
 #define DCLIP_ELAUNCH (-2)
 
 int dclip_version(void);                    /* ABI version, bumped on any signature change */
+/* 0 when the HIP runtime this library is bound to sees a device; DCLIP_ELAUNCH otherwise, with dclip_last_error_string() naming the
+ * likely cause (a second HIP runtime mapped before this one: see "Load order" above) */
+int dclip_runtime_check(void);
 const char* dclip_arch(void);               /* "gfx950" */
 const char* dclip_last_error_string(void);  /* thread-local */
 
@@ -37,8 +44,12 @@ const char* dclip_last_error_string(void);  /* thread-local */
 #define DCLIP_ACT_QUICKGELU 1 /* reference model/component/_common.py:23-25 */
 #define DCLIP_ACT_GELU 2      /* exact erf GELU: timm Mlp act, reference weight_share_model.py:177 */
 #define DCLIP_ACT_DGELU 3     /* multiply by gelu'(aux_in): backward of DCLIP_ACT_GELU from the saved pre-activation */
-#define DCLIP_ACT_MULAUX 4    /* multiply by aux_in: backward of DCLIP_ACT_GELU_SAVE */
-#define DCLIP_ACT_GELU_SAVE 5 /* DCLIP_ACT_GELU whose aux_out receives gelu'(pre-activation) instead of the pre-activation */
+#define DCLIP_ACT_MULAUX 4    /* multiply by the 8-bit gelu' in aux_in: backward of DCLIP_ACT_GELU_SAVE */
+#define DCLIP_ACT_GELU_SAVE 5 /* DCLIP_ACT_GELU whose aux_out receives gelu'(pre-activation) as 8-bit fixed point (below) */
+/* output dtype codes of dclip_gemm_nt / dclip_embed_gather / dclip_layernorm_fwd_f16 */
+#define DCLIP_OUT_BF16 0
+#define DCLIP_OUT_F32 1
+#define DCLIP_OUT_F16 2
 
 /*
  * C[M,N] = epilogue(alpha * A[M,K] · B[N,K]^T)        (nn.Linear / F.linear / x @ proj / conv-as-GEMM)
@@ -46,9 +57,13 @@ const char* dclip_last_error_string(void);  /* thread-local */
  *   A, B bf16 (lda, ldb in elements; K % 64 == 0; 16-byte aligned rows).
  *   epilogue, in order: + bias[N] (f32, may be NULL) ; if aux_out: store pre-activation as bf16 [M,N] (ld = ldc) ;
  *   activation `act` (DCLIP_ACT_DGELU multiplies by gelu'(aux_in[M,N] bf16, ld = ldc); DCLIP_ACT_GELU_SAVE stores
- *   gelu'(pre-activation) in aux_out instead, which DCLIP_ACT_MULAUX multiplies by: the training towers use that pair, the
- *   derivative being two extra instructions in the forward epilogue and a single multiply in the backward one) ;
- *   + residual[M,N] (f32, ld = ldr, may be NULL, may alias C when out_f32) ; store C as f32 (out_f32=1) or bf16.
+ *   gelu'(pre-activation) in aux_out instead — ONE BYTE per element, uint8 [M,N] with ld = ldc bytes: code q = rint((g' + 0.13) * 255 / 1.26),
+ *   value -0.13 + q * 1.26 / 255 (the derivative of the exact GELU lies in [-0.129, 1.129]; |error| <= 2.5e-3) — which
+ *   DCLIP_ACT_MULAUX multiplies by: the training towers use that pair, the derivative being a few extra instructions in the
+ *   forward epilogue and a single multiply in the backward one) ;
+ *   + residual[M,N] (ld = ldr, may be NULL; f32 with bf16 / f32 output — may alias C when the output is f32 —, f16 with f16 output — may
+ *   alias C) ; store C as bf16 / f32 / f16 (out_dtype = DCLIP_OUT_*; f16 needs act = DCLIP_ACT_NONE: the frozen teacher's in-place
+ *   residual stream, reference _common.py:124-125 under `precision: 16`, config/final_config/l_clip.yaml:64).
  *   row_group > 0 adds `rowadd` (f32 [row_group, N]) row (r % row_group) to GEMM row r: the positional-embedding
  *   add of the token embedders (reference _common.py:196-202, text_encoder.py:65-66, weight_share_model.py:344-349,
  *   :487-489); for images the caller folds class token and conv bias into the table (see dclip_token_table).
@@ -56,7 +71,7 @@ const char* dclip_last_error_string(void);  /* thread-local */
  */
 int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, float alpha, const float* bias, int act,
-                  const void* aux_in, void* aux_out, const float* residual, int64_t ldr, int out_f32,
+                  const void* aux_in, void* aux_out, const void* residual, int64_t ldr, int out_dtype,
                   int64_t row_group, const float* rowadd, float* colsum_acc, void* stream);
 
 /*
@@ -91,13 +106,11 @@ int dclip_colsum_acc(const void* X, int64_t ld, float* db, int64_t M, int64_t N,
 int dclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
                         void* y, int64_t ldy, int out_f32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                         void* stream);
-/* fwd_add: the residual add of `x = x + self.mlp(self.ln_2(x))` (reference: model/component/_common.py:123-125 ResidualAttentionBlock.forward,
- *      weight_share_model.py:180-184 MiniBlock.forward) fused into the LayerNorm that reads the sum next:
- *      xsum[r] = x[r] + delta[r] (delta bf16 [M, D] = the linear's output, bias included; xsum may be x itself), y[r] = LN(xsum[r]).
- *      The linear's GEMM then stores bf16 instead of reading and re-writing the f32 stream in its epilogue. */
-int dclip_layernorm_fwd_add(const float* x, int64_t ldx, const void* delta, int64_t ldd, float* xsum, int64_t ldxs,
-                            const float* gamma, const float* beta, void* y, int64_t ldy, float* mean, float* rstd,
-                            int64_t M, int64_t D, float eps, void* stream);
+/* the same on fp16 rows (x f16 [.., ldx]; y bf16 / f32 / f16 by out_dtype = DCLIP_OUT_*): the frozen teacher's LayerNorms, whose input is
+ * the fp16 residual stream and which compute in f32 and return the input's type (reference _common.py:14-20) */
+int dclip_layernorm_fwd_f16(const void* x, int64_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                            void* y, int64_t ldy, int out_dtype, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                            void* stream);
 int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x, int64_t ldx, const int32_t* row_index,
                         const float* gamma, const float* mean, const float* rstd, float* dx_acc, int64_t lddx,
                         void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, float* colsum_acc, int64_t M, int64_t D,
@@ -131,18 +144,6 @@ int dclip_attn_softmax_fwd(const float* S, const float* Wl, const float* Ww, voi
                            int64_t N, int64_t Np, int causal, void* stream);
 int dclip_attn_softmax_bwd(const void* dR, const void* P, const void* S, int scores_bf16, const float* Wl, const float* Ww,
                            void* dS, float* dWl, float* dWw, int64_t B, int64_t H, int64_t N, int64_t Np, void* stream);
-/*
- * Fused student attention forward (reference weight_share_model.py:88-140 MiniAttention.forward with conv_l / conv_w):
- *   ctx[(b,i), h*hd + :] = conv_w(softmax(conv_l(scale * q k^T))) v  from the packed qkv rows [B*N, 3*H*hd] (ld elements),
- *   and the tensors the backward needs: S (pre-mix scores, bf16; nullable), P (probabilities, bf16; nullable), R (mixed
- *   probabilities, bf16), each [B,H,N,Np].  The scores are written once and never read back in the forward.
- *   dclip_attn_student_fwd_supported(H, N, hd) tells whether a fused instantiation exists for the shape (the students of the
- *   shipped configs); other shapes use dclip_attn_nt + dclip_attn_softmax_fwd + dclip_attn_nn.
- */
-int dclip_attn_student_fwd_supported(int64_t H, int64_t N, int64_t hd);
-int dclip_attn_student_fwd(const void* qkv, int64_t ld, const float* Wl, const float* Ww, void* S, void* P, void* R, void* ctx,
-                           int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t Np, int64_t hd, float scale, void* stream);
-
 /*
  * Head-mixed student attention, score stage, with the score tensors kept in registers and BOTH head mixes on the matrix pipe
  * (attention_mix.hip + attn_mix_wave.h; reference weight_share_model.py:101-125).  One wave per (sample, 16 query rows):
@@ -190,6 +191,7 @@ int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo,
  * adamw                : torch.optim.AdamW step on flat f32 buffers (distil_model.py:160-162, dual_distill_model.py:194-196).
  */
 int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int dclip_cast_f16_f32(const void* src, float* dst, int64_t n, void* stream);   /* f16 -> f32 (teacher hidden-state export) */
 /* dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src (row length D) */
 int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream);
 int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream);
@@ -202,7 +204,7 @@ int dclip_token_table(const float* pos, const float* cls, const float* bias, flo
 int dclip_token_table_bwd(const float* tok_sum, float* dpos, float* dcls, float* dbias, int64_t ntok, int64_t D, int has_cls,
                           void* stream);
 int dclip_batch_sum_acc(const float* G, float* out, int64_t B, int64_t N, int64_t D, void* stream);
-int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const float* table, const float* pos, void* out, int out_f32,
+int dclip_embed_gather(const int64_t* ids, int64_t id_stride, const float* table, const float* pos, void* out, int out_dtype,
                        int64_t rows, int64_t N, int64_t D, void* stream);
 int dclip_embed_scatter_add(const int64_t* ids, const void* dx, int dx_f32, float* dtable, int64_t rows, int64_t D,
                             int64_t vocab, void* stream);

@@ -7,22 +7,20 @@ with the fields of the reference's output dataclasses (model/component/output.py
 import contextlib
 import math
 import torch
-import os
 import torch.nn.functional as F
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Rounding-matched mode (test infrastructure for tight END-TO-END gradient parity).  The HIP path stores GEMM operands as
 # bf16; against the plain fp32 oracle that costs ~1e-2 per block execution on gradients, which hides a
 # backward error of a few per cent.  Inside `with bf16_matched():` this restatement rounds to bf16 at the SAME points —
-# forward: weights, LayerNorm outputs, qkv, probabilities, mixed probabilities, context, gelu output, (with the opt-in
-# DCLIP_DEFER_RESIDUAL=1) the MLP output of every block execution whose residual add is done by the next LayerNorm, picked final row, im2row patches; backward: the gradient of every one of those tensors plus the residual-stream gradient where it enters a
-# GEMM (fc2 / proj / head / embedding outputs), the pre-mix scores, and gelu'(z) saved as bf16 — while accumulation stays
+# forward: weights, LayerNorm outputs, qkv, probabilities, mixed probabilities, context, gelu output, picked final row, im2row patches,
+# and the frozen teacher's residual stream as fp16 (the type the reference's `precision: 16` autocast keeps it in; the HIP path stores it
+# that way: DESIGN.md section 3); backward: the gradient of every one of those tensors plus the residual-stream gradient where it enters a
+# GEMM (fc2 / proj / head / embedding outputs), the pre-mix scores, and gelu'(z) saved as 8-bit fixed point — while accumulation stays
 # fp32 on both sides.  What remains is accumulation order and rare rounding flips: ~1e-3.  The arithmetic between the
 # rounding points is unchanged, and tests/test_oracle_golden.py holds this mode to the pinned fp32 oracle within bf16 noise.
 # ---------------------------------------------------------------------------------------------------------------------
 _MATCHED = False
-# the HIP path's opt-in DCLIP_DEFER_RESIDUAL (MLP output handed to the next ln_1 as bf16) adds one rounding point to the matched mode
-_DEFER = os.environ.get('DCLIP_DEFER_RESIDUAL', '0') not in ('', '0')
 
 
 @contextlib.contextmanager
@@ -62,15 +60,28 @@ def Qb(x):       # fp32 value whose GRADIENT enters a GEMM as a bf16 operand
     return _Round.apply(x, False, True) if _MATCHED else x
 
 
+def Qh(x):       # the frozen teacher's residual stream: stored as fp16 (inference only, no gradient)
+    return x.to(torch.float16).to(torch.float32) if _MATCHED else x
+
+
+# 8-bit fixed-point code of the saved gelu' (include/dclip.h, DCLIP_ACT_GELU_SAVE): q = rint((g' + 0.13) * 255 / 1.26)
+_DG_LO, _DG_STEP = -0.13, 1.26 / 255.0
+
+
+def dg_quantise(dg):
+    q = torch.clamp(torch.round(dg * (255.0 / 1.26) + 0.13 * (255.0 / 1.26)), 0.0, 255.0)
+    return q * _DG_STEP + _DG_LO
+
+
 class _GeluSave(torch.autograd.Function):
     """fc1 epilogue of the training towers (include/dclip.h DCLIP_ACT_GELU_SAVE / DCLIP_ACT_MULAUX): u = bf16(gelu(z)),
-    gelu'(z) saved as bf16, dz = bf16(du * gelu'(z))."""
+    gelu'(z) saved as 8-bit fixed point, dz = bf16(du * gelu'(z))."""
 
     @staticmethod
     def forward(ctx, z):
         cdf = 0.5 * (1.0 + torch.erf(z * 0.7071067811865476))
         dg = cdf + z * torch.exp(-0.5 * z * z) * 0.3989422804014327
-        ctx.save_for_backward(_rb(dg))
+        ctx.save_for_backward(dg_quantise(dg))
         return _rb(z * cdf)
 
     @staticmethod
@@ -127,15 +138,10 @@ def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, n
     reps = []
     for i in range(layers):
         p = f'{prefix}transformer.resblocks.{i}.'
-        x = x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}')
+        x = Qh(x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}'))
         h = Q(_ln(x, sd, p + 'ln_2'))
         u = Q(quick_gelu(_lin(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'])))
-        mlp = _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'])
-        # (matched mode under DCLIP_DEFER_RESIDUAL=1 only: the HIP path then hands the MLP output of every block but the last / an
-        #  exported one to the next ln_1 as bf16 — dclip_layernorm_fwd_add — where the reference's fp16 autocast rounds it to fp16)
-        if _DEFER and i + 1 < layers and not (need_rep and (need_layers is None or i in need_layers)):
-            mlp = Qf(mlp)
-        x = x + mlp
+        x = Qh(x + _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias']))
         if cap is not None:
             cap[f'tblock{i}.out'] = x
         if need_rep and (need_layers is None or i in need_layers):
@@ -152,9 +158,9 @@ def teacher_image_forward(sd, image, heads=None, need_layers=None, need_rep=Fals
     x = F.conv2d(Qf(image), Qf(w), stride=patch)                    # :196
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)      # :197-198
     cls = sd['visual.class_embedding'] + torch.zeros(x.shape[0], 1, width)
-    x = torch.cat([cls, x], dim=1) + sd['visual.positional_embedding']   # :199-202
+    x = Qh(torch.cat([cls, x], dim=1) + sd['visual.positional_embedding'])   # :199-202
     emb = x if need_emb else None
-    x = _ln(x, sd, 'visual.ln_pre')                                  # :208
+    x = Qh(_ln(x, sd, 'visual.ln_pre'))                              # :208
     x, reps = _teacher_blocks(x, sd, 'visual.', layers, heads, None, cap, need_layers, need_rep)
     x = Q(_ln(x, sd, 'visual.ln_post')) @ Qf(sd['visual.proj'])      # :210-213
     return dict(last_representation=x[:, 0, :], last_layer_output=x, representations=reps, embedding=emb)
@@ -170,7 +176,7 @@ def teacher_text_forward(sd, text, heads=None, need_layers=None, need_rep=False,
     width = sd['positional_embedding'].shape[1]
     layers = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('transformer.resblocks.'))
     heads = heads or width // 64            # reference utils.py:94
-    x = sd['token_embedding.weight'][text] + sd['positional_embedding']     # :65-66
+    x = Qh(sd['token_embedding.weight'][text] + sd['positional_embedding'])     # :65-66
     emb = x if need_emb else None
     x, reps = _teacher_blocks(x, sd, '', layers, heads, causal_mask(text.shape[1]), cap, need_layers, need_rep)
     x = Q(_ln(x, sd, 'ln_final')) @ Qf(sd['text_projection'])               # :69,72
@@ -218,10 +224,7 @@ def _student_blocks(x, sd, heads, repeats, use_transform, cap, need_rep=False):
             x = x + _mini_attention(h, sd, p + 'attn.', r, heads, use_transform, cap, tag)
             h = Q(_ln(x, sd, p + f'norm2.instances.{r}'))
             u = _gelu(_lin(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias']))         # timm Mlp, exact erf GELU
-            mlp = _lin(u, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], grad_operand=True)
-            if _DEFER and not (i == n_blocks - 1 and r == repeats - 1) and not need_rep:       # (matched mode only, as in _teacher_blocks)
-                mlp = Qf(mlp)
-            x = x + mlp
+            x = x + _lin(u, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], grad_operand=True)
             if cap is not None:
                 cap[tag + '.out'] = x
             if need_rep:

@@ -104,3 +104,39 @@ def test_gradscaler_skips_the_step_on_overflow():
     for n, p in m.student.named_parameters():
         if p.requires_grad:
             assert torch.equal(p.detach(), before[n]), n
+
+
+def test_fused_adamw_consumes_gradients_that_went_through_autograd():
+    """DCLIP_DP_MODE=off (tower.autograd_params): the parameter gradients are returned to autograd — p.grad are autograd's tensors, not views
+    of the tower's flat gradient buffer — and configure_optimizers() still returns FusedAdamW, which reads that buffer.  Round 4 applied
+    weight decay only in this mode (the buffer was never written).  Three steps with the shipped optimizer in both modes give the same
+    weights; zero_grad() drops autograd's gradients so that they do not accumulate across steps (reference dual_distill_model.py:194-196)."""
+    batch = _batch()
+    runs = []
+    for through_autograd in (False, True):
+        model = _build()
+        for tw in model.towers():
+            tw.autograd_params = through_autograd
+        (opt,), _ = model.configure_optimizers()
+        opt.lr = 1e-3
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.training_step(batch)
+            loss.backward()
+            if through_autograd:                       # the premise: p.grad is autograd's tensor, not a view of the tower's flat buffer
+                tw = model.towers()[0]
+                lo, hi = tw.flat_grad.data_ptr(), tw.flat_grad.data_ptr() + tw.flat_grad.numel() * 4
+                p = next(q for q in tw._params() if q is not None and q.requires_grad)
+                assert p.grad is not None and not (lo <= p.grad.data_ptr() < hi)
+            opt.step()
+        torch.cuda.synchronize()
+        runs.append({n: p.detach().clone() for n, p in model.student.named_parameters() if p.requires_grad})
+    moved = 0.0
+    init = _build()
+    for n, p0 in init.student.named_parameters():
+        if n in runs[0]:
+            moved = max(moved, (runs[0][n] - p0.detach()).abs().max().item())
+    assert moved > 1e-3                                # the optimizer really moved the weights (lr 1e-3, 3 steps)
+    for n in runs[0]:
+        d = (runs[0][n] - runs[1][n]).abs().max().item()
+        assert d <= 2e-5, (n, d)                       # (Adam divides by sqrt(v): f32-atomic ordering noise of the wgrads, nothing more)

@@ -18,7 +18,43 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(l._dll, name), name
-    assert l.dclip_version() == 3 and l.dclip_arch() == b'gfx950'
+    assert l.dclip_version() == 4 and l.dclip_arch() == b'gfx950'
+
+
+def test_loading_the_c_abi_before_torch_is_reported_in_words():
+    """include/dclip.h "Load order": PyTorch-ROCm ships its own libamdhip64 and asks for it by another name than this library's DT_NEEDED
+    entry, so a process that maps libdistillclip_hip.so FIRST and torch second holds two HIP runtimes; round 4's symptom was HIP's
+    "no ROCm-capable device is detected" from every kernel of the second one.  dclip_runtime_check() (and every failed launch) now says
+    what happened.  Child processes, no GPU needed: (a) the library alone: one runtime, and without a GPU the message names it and the
+    missing device; (b) library first, torch second: the message names both runtimes and the fix; (c) torch first (what _lib.py does):
+    one runtime."""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, 'distillclip_amd', 'libdistillclip_hip.so')
+    prog = (
+        'import ctypes, sys\n'
+        'order = sys.argv[1]\n'
+        'if order == "torch_first": import torch\n'
+        f'dll = ctypes.CDLL({so!r})\n'
+        'if order == "lib_first": import torch\n'
+        'dll.dclip_last_error_string.restype = ctypes.c_char_p\n'
+        'rc = dll.dclip_runtime_check()\n'
+        'n = sum(1 for p in {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})\n'
+        'print(rc, n, dll.dclip_last_error_string().decode())\n')
+    out = {}
+    for order in ('lib_only', 'lib_first', 'torch_first'):
+        r = subprocess.run([sys.executable, '-c', prog, order], capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rc, n, msg = r.stdout.strip().split(' ', 2) if r.stdout.strip().count(' ') >= 2 else (r.stdout.strip().split(' ') + [''])[:3]
+        out[order] = (int(rc), int(n), msg)
+    assert out['lib_only'][1] == 1 and out['torch_first'][1] == 1, out
+    rc, n, msg = out['lib_first']
+    assert n == 2 and rc == -2, out
+    assert 'HIP runtimes are mapped' in msg and 'import torch' in msg and 'BEFORE' in msg, msg
+    if not torch.cuda.is_available():                  # no GPU in this container: the single-runtime cases report the missing device, by name
+        for order in ('lib_only', 'torch_first'):
+            rc, n, msg = out[order]
+            assert rc == -2 and 'sees no usable device' in msg and 'libamdhip64' in msg, out
 
 
 def test_argument_validation_happens_on_host():

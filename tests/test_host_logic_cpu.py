@@ -160,53 +160,6 @@ def test_parameter_gradients_travel_through_autograd_only_when_an_outer_wrapper_
     assert autograd_params_mode(t) is True
 
 
-def test_persistent_gemm_ticket_walk_model_covers_every_tile_once():
-    """Model of the tile walk of gemm_nt256_kernel's persistent launches (csrc/gemm.hip: xcd_remap, `pos`, `first_free`, the per-XCD ticket
-    counters and their re-arm by the chunk's last ticket), run under random interleavings of the workgroups: every tile is processed exactly
-    once, every counter is back at zero when the launch ends, and a launch with one workgroup per tile never walks.  The kernel itself is
-    covered on the GPU (tests/test_gemm_gpu.py with DCLIP_GEMM_PERSIST=8 / 16 in tools/diag/r4_persist3.sh); this pins the arithmetic."""
-    import random
-
-    def xcd_remap(bid, nwg):
-        q, r, x = nwg >> 3, nwg & 7, bid & 7
-        return (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + (bid >> 3)
-
-    def launch(ntiles, grid, tickets, seed):
-        rnd = random.Random(seed)
-        ctr = [0] * 8
-        done = []
-        walk = grid < ntiles
-        wgs = [dict(x=b & 7, chunk=(ntiles >> 3) + (1 if (b & 7) < (ntiles & 7) else 0), ff=grid >> 3, pos=b >> 3, n=0) for b in range(grid)]
-        live = list(wgs)
-        while live:
-            w = rnd.choice(live)
-            if walk and tickets:                                   # the draw at the top of a tile
-                t = ctr[w['x']]
-                ctr[w['x']] += 1
-                nextpos = w['ff'] + t
-                if t == w['chunk'] - 1:
-                    ctr[w['x']] = 0
-            else:
-                nextpos = w['pos'] + w['ff']
-            done.append(xcd_remap(w['pos'] * 8 + w['x'], ntiles))
-            more = walk and w['pos'] < nextpos < w['chunk']
-            if more:
-                w['n'] += 1
-                more = w['n'] < w['chunk']
-            if more:
-                w['pos'] = nextpos
-            else:
-                live.remove(w)
-        assert sorted(done) == list(range(ntiles)), (ntiles, grid, tickets)
-        assert ctr == [0] * 8
-
-    for ntiles in (1, 4, 7, 8, 9, 255, 256, 257, 300, 720, 721, 1488, 2964):
-        for grid in (8, 16, 256):
-            for tickets in (0, 1):
-                for seed in range(3):
-                    launch(ntiles, min(grid, ntiles), tickets, seed)
-
-
 def test_shared_image_patches_is_a_no_op_without_two_matching_image_towers():
     """shared_image_patches (one im2row for teacher + student) only engages for CUDA f32 images and at least two image towers that cut them the
     same way; everything else — CPU tensors, one tower, text towers, different patch sizes, DCLIP_SHARE_PATCHES=0 — leaves every tower to its

@@ -10,7 +10,7 @@ shapes = [(2048, 1024, 768, 'bf16'), (2048, 1024, 768, 'qgelu'), (2048, 1024, 76
 for M, N, K, kind in shapes:
     a = torch.randn(M, K, device='cuda').bfloat16(); b = (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
     bias = torch.randn(N, device='cuda'); res = torch.randn(M, N, device='cuda'); out = torch.empty(M, N, device='cuda')
-    aux = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    aux = torch.empty(M, N, device='cuda', dtype=torch.uint8)
     def run():
         if kind == 'res': ops.gemm_nt(a, b, bias=bias, residual=res, out=out)
         elif kind == 'qgelu': ops.gemm_nt(a, b, bias=bias, act='quickgelu')
