@@ -1,0 +1,80 @@
+"""Inputs of the real-shape golden files real_b4_image1 / real_b4_textc / real_b4_336 (tools/golden/gen_golden.py, round 5: BASELINE.json
+configs[1], [2], [4] run through the reference's own modules at B = 4), rebuilt from the seeds the files carry, and the comparison of a
+gradient set with what the reference produced.  Shared by tests/test_oracle_golden.py (CPU: oracle vs reference) and
+tests/test_configs_gpu.py (HIP path vs reference, HIP path vs rounding-matched oracle)."""
+import os
+
+import numpy as np
+import torch
+
+from distillclip_amd import synth
+
+S_IMG = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24, mlp_ratio=4.0,
+             qkv_bias=True, repeated_times=2, use_transform=True)
+S_TXT = dict(depth=4, repeated_times=2, use_transform=True)
+S_TXTC = dict(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)
+FROZEN_IMAGE = ('patch_embed.proj.weight', 'cls_token', 'pos_embed')       # reference distil_model.py:200
+
+
+def T(d):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def image1_inputs(g):
+    """image.yaml: (image, teacher state, student state with the teacher's conv1 / class / positional embeddings copied in as
+    DistillModel.freeze_image_embedding does, reference distil_model.py:197-213)"""
+    seed, B = int(g['seed']), int(g['B'])
+    assert tuple(g['frozen']) == FROZEN_IMAGE
+    tsd = T(synth.teacher_image_state(seed))
+    sd = T(synth.student_image_state(seed, **S_IMG))
+    sd['patch_embed.proj.weight'] = tsd['visual.conv1.weight'].clone()
+    sd['cls_token'] = tsd['visual.class_embedding'].view(1, 1, -1).clone()
+    sd['pos_embed'] = tsd['visual.positional_embedding'].unsqueeze(0).clone()
+    return torch.from_numpy(synth.images(seed, B, 224)), tsd, sd
+
+
+def textc_inputs(g):
+    seed, B = int(g['seed']), int(g['B'])
+    return torch.from_numpy(synth.captions(seed, B)), T(synth.teacher_text_state(seed)), T(synth.student_text_state(seed, **S_TXTC))
+
+
+def l336_inputs(g):
+    seed, B = int(g['seed']), int(g['B'])
+    tsd = T(synth.teacher_image_state(seed, resolution=336))
+    tsd.update(T(synth.teacher_text_state(seed)))
+    return (torch.from_numpy(synth.images(seed, B, 336)), torch.from_numpy(synth.captions(seed, B)), tsd,
+            T(synth.student_image_state(seed, **dict(S_IMG, img_size=336))), T(synth.student_text_state(seed, **S_TXT)))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def gradient_errors(g, prefix, grads, skip=()):
+    """grads: {parameter name: gradient tensor or None}.  -> ({name: worst rel-L2 of the head / spread samples}, {name: relative error of
+    the norm}, number of parameters the file holds under `prefix`).  Parameters whose reference gradient is exactly zero are compared in
+    absolute terms against the largest gradient norm of the set (rel-L2 of noise against zero means nothing)."""
+    names = [k[len(prefix) + 7:] for k in g if k.startswith(prefix + '.gnorm.')]
+    scale = max(float(g[f'{prefix}.gnorm.{n}']) for n in names)
+    samples, norms = {}, {}
+    for n in names:
+        if n in skip:
+            continue
+        gr = grads[n].detach().float().cpu().reshape(-1).numpy()
+        ref_norm = float(g[f'{prefix}.gnorm.{n}'])
+        step = max(1, gr.size // 256)
+        worst = 0.0
+        for kind, got in (('ghead', gr[:256]), ('gspread', gr[::step][:256])):
+            ref = g[f'{prefix}.{kind}.{n}']
+            if np.linalg.norm(ref) <= 1e-7 * scale:
+                worst = max(worst, float(np.linalg.norm(got)) / scale)
+            else:
+                worst = max(worst, rel_l2(got, ref))
+        samples[n] = worst
+        norms[n] = abs(float(np.linalg.norm(gr)) - ref_norm) / (ref_norm + 1e-6 * scale)
+    return samples, norms, len(names)

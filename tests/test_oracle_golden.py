@@ -224,6 +224,104 @@ def test_real_shapes_gradients_of_every_parameter_match_the_reference(golden_dir
     assert n_checked == 68 + 44
 
 
+# ---- round 5: BASELINE.json configs[1], [2], [4] at their real shapes, pinned to reference runs (tools/golden/gen_golden.py real_image1 /
+# real_textc / real_336).  The HIP path is held to the same three files on the GPU (tests/test_configs_gpu.py). ------------------------------
+def _assert_grads(g, prefix, grads, expect, tol=5e-4):
+    import real_cases as rc
+    samples, norms, n = rc.gradient_errors(g, prefix, grads)
+    assert n == expect, (prefix, n)
+    bad = {k: v for k, v in samples.items() if v > tol}
+    assert not bad, (prefix, bad)
+    bad = {k: v for k, v in norms.items() if v > tol}
+    assert not bad, (prefix, 'norms', bad)
+
+
+def _grads(sd):
+    return {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in sd.items()}
+
+
+def test_image_yaml_real_shapes_match_the_reference(golden_dir):
+    """config/final_config/image.yaml (one image tower, freeze_embed, teacher_need_layers [0, 1, 10, 11], losses out_l1 + out_cos):
+    embeddings, loss dict and the gradient of every trainable parameter, for the shipped loss set and for the smooth objective."""
+    import real_cases as rc
+    g = rc.load(golden_dir, 'real_b4_image1.npz')
+    image, tsd, sd = rc.image1_inputs(g)
+    for n, v in sd.items():
+        v.requires_grad_(n not in rc.FROZEN_IMAGE)
+    with torch.no_grad():
+        to = oracle.teacher_image_forward(tsd, image, need_layers=[0, 1, 10, 11])
+    so = oracle.student_image_forward(sd, image, 24)
+    close(so['last_representation'], g['img1.s.last_representation'], rtol=2e-4, atol=2e-5)
+    close(to['last_representation'], g['img1.t.last_representation'], rtol=2e-4, atol=2e-5)
+    loss, res = oracle.LossOracle(['out_l1', 'out_cos'])(so, to, 'image')
+    close(loss, g['img1.loss'], rtol=2e-5)
+    for k in res:
+        close(res[k], g['img1.term.' + k], rtol=2e-5)
+    loss.backward()
+    trainable = {n: p for n, p in sd.items() if p.requires_grad}
+    _assert_grads(g, 'img1.l1cos', _grads(trainable), 68 - 3, tol=2e-3)      # (out_l1: sign(s - t) / n, piecewise constant)
+    for p in sd.values():
+        p.grad = None
+    loss2, _ = oracle.LossOracle(['out_cos'])(oracle.student_image_forward(sd, image, 24), to, 'image')
+    close(loss2, g['img1.cos.loss'], rtol=2e-5)
+    loss2.backward()
+    _assert_grads(g, 'img1.cos', _grads(trainable), 68 - 3)
+    assert all(sd[n].grad is None for n in rc.FROZEN_IMAGE)
+
+
+def test_text_yaml_real_shapes_match_the_reference(golden_dir):
+    """config/final_config/text.yaml (one text tower, compression_embedding=True, losses out_l1 + out_cos)"""
+    import real_cases as rc
+    g = rc.load(golden_dir, 'real_b4_textc.npz')
+    text, tsd, sd = rc.textc_inputs(g)
+    for v in sd.values():
+        v.requires_grad_(True)
+    with torch.no_grad():
+        to = oracle.teacher_text_forward(tsd, text)
+    so = oracle.student_text_forward(sd, text, 12)
+    close(so['last_representation'], g['txtc.s.last_representation'], rtol=2e-4, atol=2e-5)
+    close(to['last_representation'], g['txtc.t.last_representation'], rtol=2e-4, atol=2e-5)
+    loss, res = oracle.LossOracle(['out_l1', 'out_cos'])(so, to, 'text')
+    close(loss, g['txtc.loss'], rtol=2e-5)
+    for k in res:
+        close(res[k], g['txtc.term.' + k], rtol=2e-5)
+    loss.backward()
+    _assert_grads(g, 'txtc.l1cos', _grads(sd), len(sd), tol=2e-3)
+    for p in sd.values():
+        p.grad = None
+    loss2, _ = oracle.LossOracle(['out_cos'])(oracle.student_text_forward(sd, text, 12), to, 'text')
+    close(loss2, g['txtc.cos.loss'], rtol=2e-5)
+    loss2.backward()
+    _assert_grads(g, 'txtc.cos', _grads(sd), len(sd))
+
+
+def test_l_clip_336px_real_shapes_match_the_reference(golden_dir):
+    """l_clip dual at 336 px (101 tokens: the stride-32 conv floors, reference _common.py:176,196), losses out_l1 + out_cos + 0.1 cos_diff"""
+    import real_cases as rc
+    g = rc.load(golden_dir, 'real_b4_336.npz')
+    image, text, tsd, sdi, sdt = rc.l336_inputs(g)
+    for v in list(sdi.values()) + list(sdt.values()):
+        v.requires_grad_(True)
+    with torch.no_grad():
+        ti = oracle.teacher_image_forward({k: v for k, v in tsd.items() if k.startswith('visual.')}, image)
+        tt = oracle.teacher_text_forward({k: v for k, v in tsd.items() if not k.startswith('visual.')}, text)
+        to = oracle.clip_forward(ti, tt)
+    oi, ot = oracle.student_image_forward(sdi, image, 24), oracle.student_text_forward(sdt, text, 12)
+    so = oracle.clip_forward(oi, ot)
+    for tag, o in (('s_img', oi), ('s_txt', ot), ('t_img', ti), ('t_txt', tt)):
+        close(o['last_representation'], g[f'{tag}.last_representation'], rtol=2e-4, atol=2e-5)
+    close(so['i2t_logits'], g['s.i2t_logits'], rtol=2e-4, atol=2e-5)
+    loss, res = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff'], {'cos_diff': 0.1})(so, to, 'all')
+    close(loss, g['loss'], rtol=2e-5)
+    for k in res:
+        close(res[k], g['term.' + k], rtol=2e-4, atol=1e-6)
+    loss2, _ = oracle.LossOracle(['out_cos'])(so, to, 'all')
+    close(loss2, g['cos.loss'], rtol=2e-5)
+    loss2.backward()
+    _assert_grads(g, 'cos.s_img', _grads(sdi), 68)
+    _assert_grads(g, 'cos.s_txt', _grads(sdt), 44)
+
+
 def test_metrics_known_answers():
     """validation metrics restatement (oracle/metrics.py) on hand-computable cases: a permutation structure fixes every
     rank, and the diagonal scores follow from the logits in closed form."""

@@ -1,4 +1,6 @@
-"""world_size-2 rehearsal (gloo, CPU) of the data-parallel gradient exchange: same call pattern as the RCCL path."""
+"""world_size-2 and world_size-8 rehearsals (gloo, CPU) of the data-parallel gradient exchange: same call pattern as the RCCL path.
+World size 8 is the target (one 8 x MI355X node, reference l_clip.yaml:56); no multi-GPU box is available to this build, so the shard plan,
+the padded row-sparse segments, the global-negative row blocks and the launcher are exercised at that size here."""
 import os
 
 import pytest
@@ -128,6 +130,51 @@ def test_global_negative_gradient_identity():
     W, B = 2, 4
     eff = torch.cat([W * si.grad[r * B:(r + 1) * B] for r in range(W)]) / W
     assert torch.allclose(eff, si.grad)
+
+
+def _global_rows_worker(rank, world, rdzv, q):
+    """global-negative mode as the model runs it (dual_distill_model.py here, SURVEY.md 8e Collective 2): ONE fused all-gather of the four
+    [B, E] embeddings, every rank evaluates the loss of ITS ROW BLOCK against all world * B columns — here with the oracle standing in for
+    dclip_distill_loss_rows, which needs the GPU — and hands back W x (gradient rows of its own samples)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
+    import oracle
+    from distillclip_amd.parallel import gather_embeddings, check_equal_batch
+    B, E = 3, 32
+    g = torch.Generator().manual_seed(7)
+    full = {k: torch.randn(world * B, E, generator=g) for k in ('si', 'st', 'ti', 'tt')}      # the concatenated batch, same on every rank
+    mine = {k: v[rank * B:(rank + 1) * B].clone() for k, v in full.items()}
+    check_equal_batch(B, torch.device('cpu'))
+    (gsi, gst, gti, gtt), r, w = gather_embeddings([mine['si'], mine['st'], mine['ti'], mine['tt']])
+    assert (r, w) == (rank, world) and all(torch.equal(a, full[k]) for a, k in ((gsi, 'si'), (gst, 'st'), (gti, 'ti'), (gtt, 'tt')))
+    si, st = gsi.clone().requires_grad_(True), gst.clone().requires_grad_(True)
+    lc = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff', 'hard_label'], {'cos_diff': 0.1})
+    loss, _ = lc(oracle.clip_forward({'last_representation': si}, {'last_representation': st}),
+                 oracle.clip_forward({'last_representation': gti}, {'last_representation': gtt}), 'all')
+    loss.backward()
+    q.put((rank, float(loss), world * si.grad[rank * B:(rank + 1) * B].clone(), world * st.grad[rank * B:(rank + 1) * B].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_negative_row_blocks_at_world_8_equal_one_process_on_the_concatenated_batch():
+    """the parity statement of SURVEY.md 8e at the target world size: the DP AVERAGE over ranks of (W x the gradient rows a rank owns)
+    is the single-process gradient on the concatenated batch, the gathered rows arrive in rank-major order on all 8 ranks"""
+    import oracle
+    world, B, E = 8, 3, 32
+    res = sorted(_run_ranks(_global_rows_worker, world, timeout=240), key=lambda r: r[0])
+    g = torch.Generator().manual_seed(7)
+    full = {k: torch.randn(world * B, E, generator=g) for k in ('si', 'st', 'ti', 'tt')}
+    si, st = full['si'].clone().requires_grad_(True), full['st'].clone().requires_grad_(True)
+    lc = oracle.LossOracle(['out_l1', 'out_cos', 'cos_diff', 'hard_label'], {'cos_diff': 0.1})
+    loss, _ = lc(oracle.clip_forward({'last_representation': si}, {'last_representation': st}),
+                 oracle.clip_forward({'last_representation': full['ti']}, {'last_representation': full['tt']}), 'all')
+    loss.backward()
+    for rank, l, gi, gt in res:
+        assert abs(l - loss.item()) <= 1e-6 * abs(loss.item())
+        # what the tower's backward receives on rank r, divided by W by the DP average, is that rank's rows of the global gradient
+        assert torch.allclose(gi / world, si.grad[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-8)
+        assert torch.allclose(gt / world, st.grad[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-8)
 
 
 def test_grad_sync_is_a_noop_without_process_group():
@@ -289,9 +336,9 @@ def _sharded_worker(rank, world, rdzv, q):
     dist.destroy_process_group()
 
 
-def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded_world2():
-    world = 2
-    res = _run_ranks(_sharded_worker, world, timeout=90)
+@pytest.mark.parametrize('world', [2, 8])
+def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded(world):
+    res = _run_ranks(_sharded_worker, world, timeout=240)
     # expected: torch.optim.AdamW on the AVERAGED gradients, trainable entries only (what DDP + the reference's optimizer do)
     ref = _FakeTower(_TOTAL, _BUCKETS, _TRAINABLE, seed=3)
     mask = torch.zeros(_TOTAL, dtype=torch.bool)
@@ -312,11 +359,11 @@ def test_reduce_scatter_sharded_adamw_all_gather_equals_unsharded_world2():
         assert torch.equal(flat[~mask], ref.flat[~mask])               # frozen parameters untouched
         assert nshard * world < _TOTAL                                 # m / v exist for the owned shards only
     # the gathered optimizer state equals torch's (first trainable range = the first slots)
-    (_, _, st0, _), (_, _, st1, _) = sorted(res, key=lambda r: r[0])
-    assert st0.keys() == st1.keys() and len(st0) == len(_TRAINABLE)
+    states = [st for _, _, st, _ in sorted(res, key=lambda r: r[0])]
+    assert len(states) == world and all(st.keys() == states[0].keys() and len(st) == len(_TRAINABLE) for st in states)
     tstate = topt.state_dict()['state']
     for i in range(len(_TRAINABLE)):
-        for st in (st0, st1):                                          # every rank sees the full (gathered) moments
+        for st in states:                                              # every rank sees the full (gathered) moments
             assert torch.allclose(st[i]['exp_avg'], tstate[i]['exp_avg'], rtol=1e-5, atol=1e-7)
             assert torch.allclose(st[i]['exp_avg_sq'], tstate[i]['exp_avg_sq'], rtol=1e-5, atol=1e-9)
             assert float(st[i]['step']) == 3.0
@@ -367,16 +414,25 @@ def _sparse_worker(rank, world, rdzv, q):
     dist.destroy_process_group()
 
 
-def test_row_sparse_embedding_exchange_equals_dense_reduce_scatter_world2():
-    res = sorted(_run_ranks(_sparse_worker, 2, timeout=90), key=lambda r: r[0])
+@pytest.mark.parametrize('world', [2, 8])
+def test_row_sparse_embedding_exchange_equals_dense_reduce_scatter(world):
+    """(world 8: eight destination segments padded to the longest, most table rows cut by a shard boundary: 128 elements per shard, 24 per row)"""
+    res = sorted(_run_ranks(_sparse_worker, world, timeout=240), key=lambda r: r[0])
     union = torch.unique(torch.cat([o['ids'].reshape(-1) for _, o in res]))
     for rank, o in res:
-        assert torch.equal(o['sparse'], o['dense']), (rank, (o['sparse'] - o['dense']).abs().max())     # bit for bit
-        assert o['rows'] == len(union) < _SV                            # only the touched rows travelled
+        if world == 2:
+            assert torch.equal(o['sparse'], o['dense']), (rank, (o['sparse'] - o['dense']).abs().max())     # bit for bit: a + b
+        else:
+            # eight addends: a ring reduction adds them in an order that depends on where an element sits in the exchanged buffer, and the
+            # sparse and the dense exchange place the same element differently — equal up to the order of seven f32 additions
+            assert torch.allclose(o['sparse'], o['dense'], rtol=0, atol=4e-7), (rank, (o['sparse'] - o['dense']).abs().max())
+            assert torch.equal(o['sparse'] == 0, o['dense'] == 0)                                          # and exactly zero in the same places
+        assert o['rows'] == len(union) <= _SV                           # only the touched rows travelled
+    assert world > 2 or len(union) < _SV
     # ... and the untouched rows of the owned table slice are exactly zero in the shard
-    per = 1024 // 2
+    per = 1024 // world
     for rank, o in res:
-        emb = o['sparse'][128 // 2:]                                    # shard layout: block bucket first, then the embedding bucket
+        emb = o['sparse'][128 // world:]                                # shard layout: block bucket first, then the embedding bucket
         lo = rank * per
         for r in range(_SV):
             a, b = max(r * _SD, lo), min((r + 1) * _SD, lo + per)
@@ -461,6 +517,36 @@ def test_row_sparse_exchange_survives_two_forwards_a_skipped_backward_and_a_ragg
     assert all(o['ragged_rows'] == len(union) for _, o in res)           # the padding ids are not rows
 
 
+def test_shard_plan_at_world_8_partitions_every_live_bucket():
+    """the plan of the target world size on the bucket layout of the shipped l_clip students (sizes from the host-side encoder plan,
+    no device): every live bucket is cut into 8 equal owned slices that tile it in rank order, the owned trainable ranges of the ranks tile
+    the bucket's trainable ranges exactly, and every rank holds 1/8 of the exchanged elements"""
+    from distillclip_amd.parallel import _Shards
+    from distillclip_amd.model.component import RepeatVisionTransformer, RepeatTextTransformer
+    towers = [RepeatVisionTransformer(img_size=224, patch_size=32, out_dim=512, embed_dim=768, depth=6, num_heads=24, qkv_bias=True,
+                                      repeated_times=2, use_transform=True)._tower,
+              RepeatTextTransformer(depth=4, repeated_times=2, use_transform=True)._tower]
+    for tw in towers:
+        offs = tw.param_offsets()
+        total = offs[-1]
+        buckets = tw.grad_buckets()
+        assert sorted(buckets) == sorted(set(buckets)) and sum(b1 - b0 for b0, b1 in buckets) == total      # a partition of the flat buffer
+        trainable = [[0, total]]
+        plans = [_Shards(buckets, trainable, rank=r, world=8) for r in range(8)]
+        assert len({p.shard_elems for p in plans}) == 1 and plans[0].shard_elems * 8 == total
+        for i, (b0, b1) in enumerate(buckets):
+            own = [p.buckets[i][2:4] for p in plans]
+            assert own[0][0] == b0 and own[-1][1] == b1 and all(own[r][1] == own[r + 1][0] for r in range(7))
+            assert all(o1 - o0 == (b1 - b0) // 8 for o0, o1 in own)
+            assert all(p.buckets[i][5] == [(p.buckets[i][2], p.buckets[i][3])] for p in plans)
+        # frozen embeddings (image.yaml freeze_embed): the frozen ranges drop out of every rank's owned trainable ranges
+        frozen_end = offs[1]
+        plans = [_Shards(buckets, [[frozen_end, total]], rank=r, world=8) for r in range(8)]
+        covered = sorted((a, b) for p in plans for bk in p.live() for a, b in bk[5])
+        assert covered[0][0] == frozen_end and covered[-1][1] == total or covered[0][0] >= frozen_end
+        assert sum(b - a for a, b in covered) == total - frozen_end
+
+
 def test_shard_plan_rejects_indivisible_world():
     from distillclip_amd.parallel import _Shards
     with pytest.raises(ValueError, match='not divisible'):
@@ -493,6 +579,27 @@ def test_bench_self_launch_dry_run():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch', '--config', 'nope'], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_bench_self_launch_dry_run_and_hung_rank_at_8_ranks():
+    """`python bench.py --gpus 8 --dry-launch` (what the driver's SCALE run starts at N = 8): eight ranks rendezvous and rank 0 reports all
+    eight; with rank 5 hung after the collective the launcher ends non-zero inside its deadline"""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _launcher_env()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--dry-launch'], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out == {'dry_launch': True, 'n_gpus': 8, 'ranks_seen': 8, 'backend': 'gloo'}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--dry-launch', '--launch-grace', '5',
+                        '--launch-timeout', '240'], env=dict(env, DCLIP_DRY_HANG_RANK='5'), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'still running' in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert time.monotonic() - t0 < 200
 
 
 def test_launcher_rendezvous_20_times_without_retry():

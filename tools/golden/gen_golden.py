@@ -410,6 +410,132 @@ def trajectory():
     print('trajectory.npz', len(out), 'arrays; tiny losses', np.round(out['tiny.loss'], 5), 'real losses', np.round(out['real.loss'], 5))
 
 
+# ---- round 5: the remaining BASELINE.json configurations at their real shapes, pinned to the reference itself -------------------------
+S_IMG_REAL = dict(img_size=224, patch_size=32, in_chans=3, out_dim=512, embed_dim=768, depth=6, num_heads=24,
+                  mlp_ratio=4.0, qkv_bias=True, repeated_times=2, use_transform=True)
+
+
+def _every_gradient(out, prefix, module):
+    """norm, first 256 elements and 256 evenly spread elements of the gradient of every parameter that has one"""
+    for n, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(-1)
+        out[f'{prefix}.gnorm.{n}'] = np_(g.norm())
+        out[f'{prefix}.ghead.{n}'] = np_(g[:256])
+        out[f'{prefix}.gspread.{n}'] = np_(g[::max(1, g.numel() // 256)][:256])
+
+
+def _one_tower(student, teacher, x, model_type, out, tag):
+    """the arithmetic of DistillModel.forward / training_step (reference distil_model.py:82-103) for the shipped one-tower loss set
+    ['out_l1', 'out_cos'] (image.yaml:26, text.yaml:13), then the smooth objective (out_cos alone) for the gradient comparison"""
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos'])
+    ctrl = lc.get_control_output()
+    so = student(x, ctrl)
+    with torch.no_grad():
+        to = teacher(x, ctrl)
+    loss, res = lc(so, to, model_type)
+    loss.backward()
+    out[f'{tag}.loss'] = np_(loss)
+    for k, v in res.items():
+        out[f'{tag}.term.{k}'] = np_(v)
+    out[f'{tag}.s.last_representation'] = np_(so.last_representation)
+    out[f'{tag}.t.last_representation'] = np_(to.last_representation)
+    _every_gradient(out, f'{tag}.l1cos', student)
+    student.zero_grad()
+    lc2 = quiet(LossCalculator, loss_name=['out_cos'])
+    so = student(x, lc2.get_control_output())
+    loss2, _ = lc2(so, to, model_type)
+    loss2.backward()
+    out[f'{tag}.cos.loss'] = np_(loss2)
+    _every_gradient(out, f'{tag}.cos', student)
+
+
+def real_image1():
+    """BASELINE.json configs[1] = config/final_config/image.yaml at its real shapes, B = 4: ViT-B/32 image teacher with
+    need_layers [0, 1, 10, 11] (image.yaml:30) -> RepeatVisionTransformer(6 = 3 x 2, 24 heads), one-tower losses out_l1 + out_cos,
+    freeze_embed applied as DistillModel.freeze_image_embedding does (distil_model.py:197-213: the teacher's conv1 / class / positional
+    embeddings copied into patch_embed.proj.weight / cls_token / pos_embed and those three frozen).  The Lightning shell itself cannot
+    be imported here (pytorch_lightning, wandb absent): the key mapping is restated in these six lines, everything numeric is the
+    reference's modules."""
+    seed, B = 2023, 4
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    teacher = build_teacher_image(seed, 768, 12, 32, 224, 512, need_layers=[0, 1, 10, 11])
+    student = build_student_image(seed, **S_IMG_REAL)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    sw, tw = student.state_dict(), teacher.state_dict()
+    stu_keys = ['patch_embed.proj.weight', 'cls_token', 'pos_embed']
+    sw['patch_embed.proj.weight'] = tw['visual.conv1.weight']
+    sw['cls_token'] = tw['visual.class_embedding'].unsqueeze(0).unsqueeze(0)
+    sw['pos_embed'] = tw['visual.positional_embedding'].unsqueeze(0)
+    student.load_state_dict(sw)
+    for n, p in student.named_parameters():
+        if n in stu_keys:
+            p.requires_grad = False
+    out = {'seed': np.int64(seed), 'B': np.int64(B), 'frozen': np.array(stu_keys)}
+    _one_tower(student, teacher, image, 'image', out, 'img1')
+    assert not any(k.endswith(tuple('.' + f for f in stu_keys)) and '.ghead.' in k for k in out)
+    np.savez_compressed(os.path.join(OUT, 'real_b4_image1.npz'), **out)
+    print('real_b4_image1.npz', len(out), 'arrays', 'loss', float(out['img1.loss']))
+
+
+def real_textc():
+    """BASELINE.json configs[2] = config/final_config/text.yaml at its real shapes, B = 4: CLIP text teacher (12 x 512, causal) ->
+    RepeatTextTransformer(depth 4 = 2 x 2, compression_embedding=True: text.yaml:10), one-tower losses out_l1 + out_cos."""
+    seed, B = 2024, 4
+    text = torch.from_numpy(synth.captions(seed, B))
+    teacher = build_teacher_text(seed, 512, 12, 77, 49408, 512)
+    cfg = dict(depth=4, repeated_times=2, use_transform=True, compression_embedding=True)
+    student = build_student_text(seed, **cfg)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    out = {'seed': np.int64(seed), 'B': np.int64(B)}
+    _one_tower(student, teacher, text, 'text', out, 'txtc')
+    np.savez_compressed(os.path.join(OUT, 'real_b4_textc.npz'), **out)
+    print('real_b4_textc.npz', len(out), 'arrays', 'loss', float(out['txtc.loss']))
+
+
+def real_336():
+    """BASELINE.json configs[4]: l_clip dual at 336 px, B = 4.  (336 // 32)^2 + 1 = 101 tokens; no ViT-B/32@336 archive exists, so the
+    teacher's [101, 768] positional table is synthetic — built at input_resolution 320 (10 x 10 patches), the 336 px
+    images being floored by the stride-32 conv exactly as the reference's conv1 floors them (_common.py:176,196)."""
+    seed, B = 2025, 4
+    image = torch.from_numpy(synth.images(seed, B, 336))
+    text = torch.from_numpy(synth.captions(seed, B))
+    paras = dict(input_resolution=336, patch_size=32, width=768, layers=12, heads=12, output_dim=512, need_layers=None, drop_out=0.)
+    t_img = ImageEncoder(is_student=False, vit_paras=paras)
+    t_img.load_state_dict(T(synth.teacher_image_state(seed, 768, 12, 32, 336, 512)))
+    t_img.eval()
+    t_txt = build_teacher_text(seed, 512, 12, 77, 49408, 512)
+    s_img = build_student_image(seed, **dict(S_IMG_REAL, img_size=336))
+    s_txt = build_student_text(seed, depth=4, repeated_times=2, use_transform=True)
+    student = CLIPModel(True, s_img, s_txt, False)
+    teacher = CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    lc = quiet(LossCalculator, loss_name=['out_l1', 'out_cos', 'cos_diff'], loss_scale={'cos_diff': 0.1})
+    so = student(text, image, lc.get_control_output())
+    with torch.no_grad():
+        to = teacher(text, image, lc.get_control_output())
+    loss, res = lc(so, to, 'all')
+    out = {'seed': np.int64(seed), 'B': np.int64(B), 'loss': np_(loss)}
+    for k, v in res.items():
+        out['term.' + k] = np_(v)
+    for tag, o in (('s_img', so.visual_output), ('s_txt', so.text_output), ('t_img', to.visual_output), ('t_txt', to.text_output)):
+        out[f'{tag}.last_representation'] = np_(o.last_representation)
+    out['s.i2t_logits'], out['t.i2t_logits'] = np_(so.i2t_logits), np_(to.i2t_logits)
+    lc2 = quiet(LossCalculator, loss_name=['out_cos'])
+    so = student(text, image, lc2.get_control_output())
+    loss2, _ = lc2(so, to, 'all')
+    loss2.backward()
+    out['cos.loss'] = np_(loss2)
+    _every_gradient(out, 'cos.s_img', s_img)
+    _every_gradient(out, 'cos.s_txt', s_txt)
+    np.savez_compressed(os.path.join(OUT, 'real_b4_336.npz'), **out)
+    print('real_b4_336.npz', len(out), 'arrays', 'loss', float(loss))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['tiny', 'loss', 'real', 'trajectory']
@@ -423,3 +549,9 @@ if __name__ == '__main__':
         real_shapes()
     if 'real_cos' in which:
         real_shapes_cos_slices()
+    if 'real_image1' in which:
+        real_image1()
+    if 'real_textc' in which:
+        real_textc()
+    if 'real_336' in which:
+        real_336()
