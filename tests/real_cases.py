@@ -56,9 +56,13 @@ def rel_l2(a, b):
 
 
 def gradient_errors(g, prefix, grads, skip=()):
-    """grads: {parameter name: gradient tensor or None}.  -> ({name: worst rel-L2 of the head / spread samples}, {name: relative error of
-    the norm}, number of parameters the file holds under `prefix`).  Parameters whose reference gradient is exactly zero are compared in
-    absolute terms against the largest gradient norm of the set (rel-L2 of noise against zero means nothing)."""
+    """grads: {parameter name: gradient tensor}.  -> ({name: error of the 512-element sample (first 256 elements + 256 spread over the tensor)},
+    {name: relative error of the norm}, number of parameters the file holds under `prefix`).
+    Sample error = |got - ref| / max(|ref|, sqrt(512) * RMS of the whole reference gradient): the plain rel-L2 of the sample when the sample is
+    as large as the tensor's typical entries, and an error relative to the TENSOR's scale when the sampled entries happen to be small (the
+    first 256 inputs of head.weight's row 0 are 16 x below that tensor's RMS: rel-L2 against such a sample measures bf16 noise of the other
+    entries' magnitude, 7.7e-2 where the same error is 5e-3 of the tensor's scale).  Norms are compared against the largest norm of the set
+    when the reference norm is (near) zero."""
     names = [k[len(prefix) + 7:] for k in g if k.startswith(prefix + '.gnorm.')]
     scale = max(float(g[f'{prefix}.gnorm.{n}']) for n in names)
     samples, norms = {}, {}
@@ -68,13 +72,9 @@ def gradient_errors(g, prefix, grads, skip=()):
         gr = grads[n].detach().float().cpu().reshape(-1).numpy()
         ref_norm = float(g[f'{prefix}.gnorm.{n}'])
         step = max(1, gr.size // 256)
-        worst = 0.0
-        for kind, got in (('ghead', gr[:256]), ('gspread', gr[::step][:256])):
-            ref = g[f'{prefix}.{kind}.{n}']
-            if np.linalg.norm(ref) <= 1e-7 * scale:
-                worst = max(worst, float(np.linalg.norm(got)) / scale)
-            else:
-                worst = max(worst, rel_l2(got, ref))
-        samples[n] = worst
+        got = np.concatenate([gr[:256], gr[::step][:256]]).astype(np.float64)
+        ref = np.concatenate([g[f'{prefix}.ghead.{n}'], g[f'{prefix}.gspread.{n}']]).astype(np.float64)
+        typical = np.sqrt(len(ref)) * max(ref_norm, 1e-7 * scale) / np.sqrt(gr.size)
+        samples[n] = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), typical))
         norms[n] = abs(float(np.linalg.norm(gr)) - ref_norm) / (ref_norm + 1e-6 * scale)
     return samples, norms, len(names)
