@@ -156,23 +156,25 @@ __device__ __forceinline__ void wave_stage(const bf16_t* __restrict__ G, int64_t
 // transposed (O^T = V^T P^T) lane (query c, group g) ends up with the 4 DT CONSECUTIVE output columns (4 DT) g .. + 4 DT - 1 of its
 // query: 16- / 32-byte row-contiguous stores instead of 8-byte pieces on 64 different lines per instruction.
 template <int ROWB, int DT>
-__device__ __forceinline__ void wave_stage_perm4(const bf16_t* __restrict__ G, int64_t ld, int rows_valid, int rows, char* tile, int lane) {
+__device__ __forceinline__ void wave_stage_perm4(const bf16_t* __restrict__ G, int64_t ld, int rows_valid, int rows, char* tile, int lane,
+                                                 int row0 = 0) {
+    // stages tile rows [row0, rows)
     constexpr int cpr = DT * 2;                // 16-byte chunks per row (HD = 16 DT)
     constexpr int BATCH = 8;                   // loads in flight per lane: a load -> write loop pays one HBM round trip per chunk
-    const int total = rows * cpr;
+    const int total = (rows - row0) * cpr;
     for (int base = 0; base < total; base += BATCH * 64) {
         u32x4 v[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int idx = base + k * 64 + lane;
-            const int r = idx / cpr, c = idx - r * cpr;
+            const int r = row0 + idx / cpr, c = idx % cpr;
             v[k] = u32x4{0u, 0u, 0u, 0u};
             if (idx < total && r < rows_valid) v[k] = *(const u32x4*)(G + (int64_t)r * ld + c * 8);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int idx = base + k * 64 + lane;
-            const int r = idx / cpr, c = idx - r * cpr;
+            const int r = row0 + idx / cpr, c = idx % cpr;
             const int q0 = 2 * c, q1 = 2 * c + 1;
             const int p0 = 4 * (q0 % DT) + q0 / DT, p1 = 4 * (q1 % DT) + q1 / DT;
             if (idx < total) {
@@ -259,25 +261,35 @@ struct AttnFused {
     bf16_t* ctx; int64_t ldc;
     int B, H, N, causal;
     float scale;
+    int split;                           // waves per (b, h) problem: 1, or 2 that share the V tile and take alternate query tiles
 };
 
-// NTM = 16-key tiles the instance holds registers for (4: N <= 64, 5: N <= 80, 8: N <= 128); the K fragments and score tiles scale
-// with it, and at NTM = 4 / 5 three waves per SIMD fit where the N = 128 sizing allowed two
+// NTM = 16-key tiles the instance holds registers for (4: N <= 64, 5: N <= 80, 7: N <= 112, 8: N <= 128); the K fragments and score tiles
+// scale with it, and at NTM = 4 / 5 three waves per SIMD fit where the N = 128 sizing allowed two.
+// LDS (round 5): the V and P tiles hold 16 x ceil(N / 16) key rows, not the sequence padded to 32 — an odd number of key tiles ends in
+// ONE v_mfma_f32_16x16x16_bf16 step instead of a half-empty 32-key step —, and the launch picks the workgroup size (4, 2 or 1 waves) that
+// puts the most waves on a CU: at N = 101 (l_clip at 336 px) a wave needs 21.8 KB instead of 24.8 and runs in one-wave workgroups, 7 per
+// CU where the four-wave workgroup of 99 KB left ONE per CU (151 us for the ViT-B/32 teacher against 38.7 at N = 50: 3.9 x for 2 x tokens).
 template <int HD, int NTM>
-__global__ __launch_bounds__(256, NTM <= 5 ? 3 : 2) void attn_fused_fwd_kernel(AttnFused p) {
+__global__ __launch_bounds__(256, NTM <= 7 ? 3 : 2) void attn_fused_fwd_kernel(AttnFused p) {
     constexpr int VROWB = HD * 2 + 32;
     constexpr int KS = HD / 32, DT = HD / 16, KSM = (NTM + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6, split = p.split, ppw = nw / split;      // ppw: problems per workgroup
     const int nprob = p.B * p.H;
-    const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
-    const bool live = blockIdx.x * 4 + wave < nprob;
+    const int slot = wave / split, part = wave - slot * split;
+    const int prob = min((int)blockIdx.x * ppw + slot, nprob - 1);
+    const bool live = (int)blockIdx.x * ppw + slot < nprob;
     const int b = prob / p.H, h = prob % p.H;
     const int D = p.H * HD;
-    const int n32 = (p.N + 31) & ~31, nt = (p.N + 15) >> 4, nks = n32 >> 5;
-    const int prowb = n32 * 2 + 16;
-    char* vt = smem + wave * (n32 * VROWB + 16 * prowb);
-    char* pt = vt + n32 * VROWB;
+    constexpr bool ODD = (NTM & 1) != 0;              // odd instances serve exactly NTM key tiles: whole 32-key steps + one 16-key step
+    const int nt = (p.N + 15) >> 4;
+    const int nrows = ODD ? nt * 16 : ((nt + 1) & ~1) * 16, nks = ODD ? nt >> 1 : (nt + 1) >> 1;
+    const int prowb = nrows * 2 + 16;
+    // LDS: [problems per workgroup] V tiles, then [waves] P tiles
+    char* vt = smem + slot * (nrows * VROWB);
+    char* pt = smem + ppw * (nrows * VROWB) + wave * (16 * prowb);
     const bf16_t* Q = p.qkv + (int64_t)b * p.N * p.ldq + h * HD;
     const bf16_t* K = Q + D;
     const bf16_t* V = Q + 2 * D;
@@ -292,22 +304,28 @@ __global__ __launch_bounds__(256, NTM <= 5 ? 3 : 2) void attn_fused_fwd_kernel(A
         }
     bf16x8 qf[KS], qn[KS];
     {
-        const int ia = min(fr, p.N - 1);
+        const int ia = min(part * 16 + fr, p.N - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Q + (int64_t)ia * p.ldq + ks * 32 + fk);
     }
     // V last: its loads join the K / Q requests already in flight, and only its LDS writes wait
-    wave_stage_perm4<VROWB, DT>(V, p.ldq, p.N, n32, vt, lane);
+    {   // the waves of a problem stage disjoint row ranges of its V tile
+        const int per = ((nrows / split) + 15) & ~15;
+        wave_stage_perm4<VROWB, DT>(V, p.ldq, p.N, min(nrows, (part + 1) * per), vt, lane, part * per);
+    }
     for (int idx = lane; idx < 16 * prowb / 4; idx += 64) ((unsigned*)pt)[idx] = 0u;
     __syncthreads();
-    for (int it = 0; it < nt; ++it) {
-        if (it + 1 < nt) {
-            const int ia = min((it + 1) * 16 + fr, p.N - 1);
+    for (int it = part; it < nt; it += split) {
+        if (it + split < nt) {
+            const int ia = min((it + split) * 16 + fr, p.N - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qn[ks] = *(const bf16x8*)(Q + (int64_t)ia * p.ldq + ks * 32 + fk);
         }
         const int i = it * 16 + fr;                         // this lane's query
-        // S^T tiles: acc[jt][r] = score(query i, key jt*16 + 4g + r)
+        // S^T tiles: acc[jt][r] = raw score(query i, key jt*16 + 4g + r); the scale rides in the exponent's fma (scale > 0: the maximum of
+        // the raw scores is the maximum of the scaled ones), masked keys are -inf and come out of exp2 as 0, and the probabilities are
+        // stored UNNORMALISED (e in [0, 1]: the same relative bf16 precision) with 1 / sum applied to the 4 DT outputs instead of to
+        // every one of the N probabilities: 4.5 vector instructions per score element where the first version spent ~10
         f32x4 st[NTM];
         float m = -INFINITY;
 #pragma unroll
@@ -316,39 +334,38 @@ __global__ __launch_bounds__(256, NTM <= 5 ? 3 : 2) void attn_fused_fwd_kernel(A
             if (jt < nt && (!p.causal || jt <= it)) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[ks], st[jt], 0, 0, 0);
+                if (jt * 16 + 16 > p.N || (p.causal && jt == it)) {        // (wave-uniform: only the last key tile / the diagonal tile mask)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = jt * 16 + g * 4 + r;
-                    const bool ok = j < p.N && (!p.causal || j <= i);
-                    st[jt][r] = ok ? st[jt][r] * p.scale : -INFINITY;
-                    m = fmaxf(m, st[jt][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = jt * 16 + g * 4 + r;
+                        const bool ok = j < p.N && (!p.causal || j <= i);
+                        st[jt][r] = ok ? st[jt][r] : -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, st[jt][r]);
             } else {
                 st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
         }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
+        const float c2 = p.scale * 1.4426950408889634f, nm = -m * c2;      // (key 0 is never masked: m is finite)
         float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NTM; ++jt)
             if (jt < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = st[jt][r] == -INFINITY ? 0.f : __expf(st[jt][r] - m);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(st[jt][r], c2, nm));
                     st[jt][r] = e;
                     sum += e;
                 }
+                *(bf16x4*)(pt + fr * prowb + (jt * 16 + g * 4) * 2) = bf16x4{f2bf(st[jt][0]), f2bf(st[jt][1]), f2bf(st[jt][2]), f2bf(st[jt][3])};
             }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
-#pragma unroll
-        for (int jt = 0; jt < NTM; ++jt)
-            if (jt < nt) {
-                bf16x4 pv = {f2bf(st[jt][0] * inv), f2bf(st[jt][1] * inv), f2bf(st[jt][2] * inv), f2bf(st[jt][3] * inv)};
-                *(bf16x4*)(pt + fr * prowb + (jt * 16 + g * 4) * 2) = pv;
-            }
         // wave-private tile, in-order DS queue: only the compiler has to keep the order (a workgroup-scope release fence would also
         // wait for vmcnt(0), i.e. for the next tile's query fragments that were requested at the top of the iteration)
         __builtin_amdgcn_wave_barrier();
@@ -366,14 +383,25 @@ __global__ __launch_bounds__(256, NTM <= 5 ? 3 : 2) void attn_fused_fwd_kernel(A
                 for (int d = 0; d < DT; ++d)
                     oc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VROWB>(vt, ks * 32, d * 16, lane), pf, oc[d], 0, 0, 0);
             }
+        if (ODD && (nt & 1) && (!p.causal || (nt - 1) * 16 <= it * 16 + 15)) {
+            // the last, odd key tile: 16 keys, lane (column, g) holds k = 4 g .. 4 g + 3 of both operands
+            const int r0 = (nt - 1) * 16;
+            const s16x4 pf = *(const s16x4*)(pt + fr * prowb + (r0 + g * 4) * 2);
+            const int q4 = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + (r0 + 4 * g + q4) * VROWB + (d * 16 + 4 * pp) * 2));
+                oc[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, oc[d], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         if (live && i < p.N) {
             // (columns permuted when V was staged: this lane holds the 4 DT consecutive columns from (4 DT) g of query i)
             bf16_t* o = p.ctx + ((int64_t)b * p.N + i) * p.ldc + h * HD + g * (4 * DT);
 #pragma unroll
             for (int d = 0; d < DT; d += 2)
-                *(bf16x8*)(o + d * 4) = bf16x8{f2bf(oc[d][0]), f2bf(oc[d][1]), f2bf(oc[d][2]), f2bf(oc[d][3]),
-                                                f2bf(oc[d + 1][0]), f2bf(oc[d + 1][1]), f2bf(oc[d + 1][2]), f2bf(oc[d + 1][3])};
+                *(bf16x8*)(o + d * 4) = bf16x8{f2bf(oc[d][0] * inv), f2bf(oc[d][1] * inv), f2bf(oc[d][2] * inv), f2bf(oc[d][3] * inv),
+                                                f2bf(oc[d + 1][0] * inv), f2bf(oc[d + 1][1] * inv), f2bf(oc[d + 1][2] * inv), f2bf(oc[d + 1][3] * inv)};
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -1052,16 +1080,35 @@ extern "C" int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int
     DCLIP_REQUIRE(qkv && ctx && B > 0 && H > 0 && N > 0 && N <= NMAX, "dclip_attn_fused_fwd: bad argument (N <= %d)", NMAX);
     DCLIP_REQUIRE(hd == 32 || hd == 64, "dclip_attn_fused_fwd: head dim must be 32 or 64 (got %ld)", (long)hd);
     DCLIP_REQUIRE(ldq % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "dclip_attn_fused_fwd: misaligned buffers");
-    AttnFused p{(const bf16_t*)qkv, ldq, (bf16_t*)ctx, ldc, (int)B, (int)H, (int)N, causal, scale};
+    AttnFused p{(const bf16_t*)qkv, ldq, (bf16_t*)ctx, ldc, (int)B, (int)H, (int)N, causal, scale, 1};
     TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd, 8.0 * B * H * N * hd, stream, (int)(B * H), (int)N, (int)hd, 4);
-    const dim3 grid((unsigned)((B * H + 3) / 4));
-    const int n32 = ((int)N + 31) & ~31;
-    const size_t lds = (size_t)4 * (n32 * (hd * 2 + 32) + 16 * (n32 * 2 + 16));
     hipStream_t st = (hipStream_t)stream;
     const int ntile = ((int)N + 15) / 16;
-#define FUSED_LAUNCH(HDv, NTv) hipLaunchKernelGGL((attn_fused_fwd_kernel<HDv, NTv>), grid, dim3(256), lds, st, p)
-    if (hd == 32) { if (ntile <= 4) FUSED_LAUNCH(32, 4); else if (ntile <= 5) FUSED_LAUNCH(32, 5); else FUSED_LAUNCH(32, 8); }
-    else { if (ntile <= 4) FUSED_LAUNCH(64, 4); else if (ntile <= 5) FUSED_LAUNCH(64, 5); else FUSED_LAUNCH(64, 8); }
+    // an instance holds registers for NT key tiles; odd tile counts need an instance with the 16-key tail step (NT odd)
+    const int NT = ntile <= 4 ? 4 : (ntile == 5 ? 5 : (ntile == 7 ? 7 : 8));
+    const int nrows = (NT & 1) ? ntile * 16 : ((ntile + 1) & ~1) * 16;            // (even instances: whole 32-key steps, zero rows behind N)
+    const size_t vtile = (size_t)nrows * (hd * 2 + 32), ptile = 16 * ((size_t)nrows * 2 + 16);
+    // workgroup shape: `ppw` problems of `split` waves each (split = 2: two waves share a problem's V tile and take alternate query
+    // tiles), whichever puts the most waves on a CU (160 KB of LDS; registers allow 12 / 8 waves: launch bounds); ties go to the split
+    // form, which also halves the dependent chain of a problem
+    const int reg_cap = NT <= 7 ? 12 : 8;
+    int nw = 4, split = 1, best = -1;
+    for (int sp = 2; sp >= 1; --sp) {
+        if (sp == 2 && ntile < 2) continue;
+        for (int ppw = 4 / sp; ppw >= 1; ppw >>= 1) {
+            const size_t wg = ppw * vtile + (size_t)ppw * sp * ptile;
+            int on_cu = (int)((160 * 1024) / wg) * ppw * sp;
+            on_cu = on_cu > reg_cap ? reg_cap : on_cu;
+            if (on_cu > best) { best = on_cu; nw = ppw * sp; split = sp; }
+        }
+    }
+    p.split = split;
+    const int ppw = nw / split;
+    const dim3 grid((unsigned)((B * H + ppw - 1) / ppw));
+    const size_t lds = ppw * vtile + (size_t)nw * ptile;
+#define FUSED_LAUNCH(HDv, NTv) hipLaunchKernelGGL((attn_fused_fwd_kernel<HDv, NTv>), grid, dim3(64 * nw), lds, st, p)
+    if (hd == 32) { if (NT == 4) FUSED_LAUNCH(32, 4); else if (NT == 5) FUSED_LAUNCH(32, 5); else if (NT == 7) FUSED_LAUNCH(32, 7); else FUSED_LAUNCH(32, 8); }
+    else { if (NT == 4) FUSED_LAUNCH(64, 4); else if (NT == 5) FUSED_LAUNCH(64, 5); else if (NT == 7) FUSED_LAUNCH(64, 7); else FUSED_LAUNCH(64, 8); }
 #undef FUSED_LAUNCH
     return dclip_check_launch("dclip_attn_fused_fwd");
 }

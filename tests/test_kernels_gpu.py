@@ -162,9 +162,12 @@ def test_attention_softmax_stage(B, N, H, mix, causal):
 
 @pytest.mark.parametrize('B,N,H,hd,causal', [(3, 17, 2, 64, False), (2, 13, 2, 64, True), (5, 50, 12, 64, False),
                                              (3, 77, 8, 64, True), (2, 101, 12, 64, False), (3, 50, 4, 32, False),
-                                             (2, 128, 2, 64, True), (1, 1, 2, 64, False)])
+                                             (2, 128, 2, 64, True), (1, 1, 2, 64, False), (7, 101, 12, 64, True), (3, 112, 4, 32, False),
+                                             (2, 97, 8, 32, True), (3, 33, 4, 64, True), (2, 80, 8, 32, False), (5, 96, 2, 64, True), (9, 65, 4, 32, False)])
 def test_attention_fused_forward(B, N, H, hd, causal):
-    """fused teacher attention (scores / probabilities never in HBM) vs torch fp32 on the same bf16 q, k, v"""
+    """fused teacher attention (scores / probabilities never in HBM) vs torch fp32 on the same bf16 q, k, v; every key-tile count 1..8,
+    incl. the odd ones whose last tile is a 16-key MFMA step (5: N = 77 / 80, 7: N = 101 / 112 / 97) and the workgroup sizes the launch
+    picks for them (round 5), causal and not, more (b, h) problems than one workgroup holds"""
     from distillclip_amd import ops
     D = H * hd
     qkv = _qkv(B, N, H, hd, 31)
