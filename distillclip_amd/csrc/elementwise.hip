@@ -508,6 +508,53 @@ extern "C" int dclip_gather_rows(const float* src, int64_t ld, const int32_t* id
     return dclip_check_launch("dclip_gather_rows");
 }
 
+// several ranges in one launch (blockIdx.y = range): the sharded data-parallel step updates one owned slice per gradient bucket — 9 launches
+// of ~20 us each per step for the two l_clip students where two whole-tower launches do the same bytes
+struct AdamwRanges { float4* p[DCLIP_ADAMW_MAX_RANGES]; float4* g[DCLIP_ADAMW_MAX_RANGES]; float4* m[DCLIP_ADAMW_MAX_RANGES]; float4* v[DCLIP_ADAMW_MAX_RANGES]; int64_t n4[DCLIP_ADAMW_MAX_RANGES]; };
+__global__ __launch_bounds__(256) void adamw4_multi_kernel(AdamwRanges r, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                           int zero_grad) {
+    const int k = blockIdx.y;
+    float4* __restrict__ p = r.p[k]; float4* __restrict__ g = r.g[k]; float4* __restrict__ m = r.m[k]; float4* __restrict__ v = r.v[k];
+    const int64_t n4 = r.n4[k];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    for (;;) {
+        const int64_t nx = i + stride;
+        const bool more = nx < n4;
+        float4 pn = pi, gn = gi, mn = mi, vn = vi;
+        if (more) { pn = p[nx]; gn = g[nx]; mn = m[nx]; vn = v[nx]; }
+        adamw_elem(pi.x, gi.x, mi.x, vi.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.y, gi.y, mi.y, vi.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.z, gi.z, mi.z, vi.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adamw_elem(pi.w, gi.w, mi.w, vi.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (!more) break;
+        i = nx; pi = pn; gi = gn; mi = mn; vi = vn;
+    }
+}
+
+extern "C" int dclip_adamw_multi(float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n, int32_t count, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t step, int zero_grad, void* stream) {
+    DCLIP_REQUIRE(p && g && m && v && n && count > 0 && count <= DCLIP_ADAMW_MAX_RANGES && step >= 1, "dclip_adamw_multi: bad argument (1..%d ranges)", DCLIP_ADAMW_MAX_RANGES);
+    AdamwRanges r;
+    int64_t longest = 0;
+    for (int k = 0; k < count; ++k) {
+        DCLIP_REQUIRE(p[k] && g[k] && m[k] && v[k] && n[k] > 0 && n[k] % 4 == 0 && ((((uintptr_t)p[k] | (uintptr_t)g[k] | (uintptr_t)m[k] | (uintptr_t)v[k]) & 15) == 0),
+                      "dclip_adamw_multi: range %d must be non-empty, a multiple of 4 elements and 16-byte aligned", k);
+        r.p[k] = (float4*)p[k]; r.g[k] = (float4*)g[k]; r.m[k] = (float4*)m[k]; r.v[k] = (float4*)v[k]; r.n4[k] = n[k] / 4;
+        longest = r.n4[k] > longest ? r.n4[k] : longest;
+    }
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    const int per_range = 8192 / count < 256 ? 256 : 8192 / count;          // (grid-stride loop: the longest range sets the width, capped)
+    hipLaunchKernelGGL(adamw4_multi_kernel, dim3(grid_for(longest, 256, per_range), (unsigned)count), dim3(256), 0, (hipStream_t)stream, r, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, zero_grad);
+    return dclip_check_launch("dclip_adamw_multi");
+}
+
 extern "C" int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, int64_t step, int zero_grad, void* stream) {
     DCLIP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dclip_adamw: bad argument");

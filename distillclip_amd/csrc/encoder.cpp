@@ -344,16 +344,15 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
 }
 
 // The backward starts from a residual-stream gradient that is non-zero in B of the M rows (the picked class / EOT rows): its f32
-// accumulator, the bf16 copy and the fc2 operand slot of the last execution start as zeros.  Those ~2 x M x D x 4 bytes of fills
-// used to open dclip_encoder_backward, i.e. sat on the critical path right after the loss; issued here, at the end of the training
-// forward, they run on the tower's stream while the other towers finish and the loss is evaluated (the buffers are not touched by
-// the forward).
+// accumulator and the fc2 operand slot of the last execution start as zeros.  Those fills used to open dclip_encoder_backward, i.e. sat
+// on the critical path right after the loss; issued at the end of the training forward, they run on the tower's stream while the other
+// towers finish and the loss is evaluated (the buffers are not touched by the forward).  (Round 5: the bf16 copy w.Gb is no longer
+// cleared — every row of it is written by the first execution's LayerNorm backward before anything reads it.)
 static int clear_backward_seeds(const Plan& p, const Work& w, int64_t M, void* st) {
     const int64_t D = p.D;
     hipStream_t hs = (hipStream_t)st;
     bf16_t* gb_last = w.gb_f2 + (int64_t)(p.R - 1) * M * D;
-    if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(w.Gb, 0, (size_t)M * D * 2, hs) != hipSuccess ||
-        hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) {
+    if (hipMemsetAsync(w.G, 0, (size_t)M * D * 4, hs) != hipSuccess || hipMemsetAsync(gb_last, 0, (size_t)M * D * 2, hs) != hipSuccess) {
         dclip_set_error("dclip_encoder: clearing the backward seeds failed");
         return DCLIP_ELAUNCH;
     }

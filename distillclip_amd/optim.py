@@ -46,11 +46,30 @@ class FusedAdamW:
             r = self._fixed_ranges[id(tw)] = [list(x) for x in tw.trainable_ranges()]
         return r
 
-    def _adamw(self, p, g, m, v, zero_grad, st):
-        """p, g, m, v: equally long 1-D f32 views.  (tests/test_parallel_cpu.py substitutes a torch version to rehearse the
+    def _adamw_hip(self, p, g, m, v, zero_grad, st):
+        """p, g, m, v: equally long 1-D f32 views.  (tests/test_parallel_cpu.py substitutes a torch version as `_adamw` to rehearse the
         sharded bookkeeping over gloo; the product path is the HIP kernel.)"""
         lib().dclip_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
+
+    _adamw = _adamw_hip
+
+    def _adamw_many(self, items, zero_grad, st):
+        """items: [(p, g, m, v)] of equally long 1-D f32 views — ONE dclip_adamw_multi launch per 24 ranges (the sharded step has one
+        owned slice per gradient bucket: nine launches per step for the two l_clip students became one per tower)"""
+        import ctypes
+        if type(self)._adamw is not FusedAdamW._adamw_hip or any(p.numel() % 4 or (p.data_ptr() | g.data_ptr() | m.data_ptr() | v.data_ptr()) % 16
+                                                                  for p, g, m, v in items):
+            for p, g, m, v in items:
+                self._adamw(p, g, m, v, zero_grad, st)
+            return
+        for i in range(0, len(items), 24):
+            chunk = items[i:i + 24]
+            n = len(chunk)
+            arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in chunk])
+            lens = (ctypes.c_int64 * n)(*[t[0].numel() for t in chunk])
+            lib().dclip_adamw_multi(arr(0), arr(1), arr(2), arr(3), lens, n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                    self.weight_decay, self.step_count, 1 if zero_grad else 0, st)
 
     def zero_grad(self, set_to_none=False):
         from .model.component._tower import autograd_params_mode
@@ -124,14 +143,20 @@ class FusedAdamW:
         works = []
         with sync._On(s):
             st = s.cuda_stream if s is not None else None
-            for i, b in enumerate(tw.dp.buckets):
+            items = []
+            for b in tw.dp.buckets:
                 if b is None:
                     continue
                 b0, b1, o0, o1, off, own_tr = b
                 for a, e in own_tr:
                     lo, hi = off + a - o0, off + e - o0
-                    self._adamw(tw.flat[a:e], tw.gshard[lo:hi], m[lo:hi], v[lo:hi], False, st)
-                works.append(all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True, group=grp))
+                    items.append((tw.flat[a:e], tw.gshard[lo:hi], m[lo:hi], v[lo:hi]))
+            if items:
+                self._adamw_many(items, False, st)
+            for b in tw.dp.buckets:
+                if b is not None:
+                    b0, b1, o0, o1, off, own_tr = b
+                    works.append(all_gather_flat(tw.flat[b0:b1], tw.flat[o0:o1], async_op=True, group=grp))
             for w in works:
                 if w is not None:
                     w.wait()
@@ -181,8 +206,7 @@ class FusedAdamW:
                 st = stream.cuda_stream
                 if through_autograd:
                     self._pack_autograd_grads(tw)
-                for b, e in self._ranges(tw):
-                    self._adamw(tw.flat[b:e], tw.flat_grad[b:e], m[b:e], v[b:e], zero_grad, st)
+                self._adamw_many([(tw.flat[b:e], tw.flat_grad[b:e], m[b:e], v[b:e]) for b, e in self._ranges(tw)], zero_grad, st)
                 tw.wcache_dirty = True
                 tw._grad_clean = bool(zero_grad) and self._ranges_cover_everything(tw)
                 if overlap and self.refresh_cache_in_step:

@@ -212,6 +212,11 @@ int dclip_pick_index(const int64_t* ids, int64_t id_stride, int32_t* idx, int64_
 int dclip_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t rows, int64_t D, void* stream);
 int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int64_t step, int zero_grad, void* stream);   /* zero_grad: g := 0 once consumed */
+/* the same step on `count` <= DCLIP_ADAMW_MAX_RANGES ranges in ONE launch (HOST arrays of device pointers and lengths; every range a
+ * multiple of 4 elements, 16-byte aligned): the sharded data-parallel optimizer updates one owned slice per gradient bucket */
+#define DCLIP_ADAMW_MAX_RANGES 24
+int dclip_adamw_multi(float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n, int32_t count, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int64_t step, int zero_grad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused distillation loss, forward + backward.

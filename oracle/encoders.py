@@ -126,8 +126,14 @@ def _teacher_attention(h, sd, p, heads, mask, cap, tag):
     scores = q @ k.transpose(-1, -2) / math.sqrt(hd)
     if mask is not None:
         scores = scores + mask
-    probs = Qf(scores.softmax(dim=-1))
-    ctx = Q((probs @ v).permute(0, 2, 1, 3).reshape(B, N, D))
+    if _MATCHED:
+        # the HIP kernel (attn_fused_fwd, round 5) keeps the probabilities UNNORMALISED in bf16 — e = exp(s - max), the row maximum exactly 1 —
+        # and applies 1 / sum(e) (f32, over the unrounded e) to the value product: same arithmetic, the rounding point moved
+        e = (scores - scores.amax(dim=-1, keepdim=True)).exp()
+        ctx = (Qf(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        ctx = scores.softmax(dim=-1) @ v
+    ctx = Q(ctx.permute(0, 2, 1, 3).reshape(B, N, D))
     if cap is not None:
         cap[tag + '.ctx'] = ctx
     return _lin(ctx, sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'])
