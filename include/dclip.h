@@ -384,7 +384,12 @@ int dclip_encoder_last_layer_output(const dclip_encoder* enc, int64_t B, const v
  * `bucket` has been enqueued on `stream` (an event recorded on `stream` inside the callback marks the bucket complete): the
  * data-parallel exchange of that bucket may start while the rest of the backward runs (reference: Lightning DDP's bucketed
  * all-reduce from autograd hooks, config/final_config/l_clip.yaml:56 strategy ddp_find_unused_parameters_false).
- * Buckets complete in index order; see dclip_encoder_grad_bucket. */
+ * Buckets complete in index order; see dclip_encoder_grad_bucket.
+ * Seeds: the backward starts from a residual-stream gradient accumulator (and one bf16 operand slot) that must be zero.  The training
+ * forward clears them at its end (beside the other towers' work) and the handle remembers the workspace it did that for; a backward that
+ * does not find ITS workspace there — a second backward on one forward, a retry, another workspace used in between — clears them itself.
+ * Either way one call = the gradients of the most recent training forward of that workspace for the given d_*; gradients ACCUMULATE (+=)
+ * into `grads` as everywhere. */
 typedef void (*dclip_bucket_cb)(void* user, int32_t bucket);
 int dclip_encoder_backward(const dclip_encoder* enc, const void* input, int64_t B, const void* const* params,
                            void* const* grads, const void* wcache, void* workspace, size_t ws_bytes,

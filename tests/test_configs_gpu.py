@@ -132,29 +132,8 @@ def test_l_clip_336px_dual():
     for got, want, tag in ((so_.visual_output, oi, 's_img'), (so_.text_output, ot, 's_txt'), (to_.visual_output, ti, 't_img'),
                            (to_.text_output, tt, 't_txt')):
         assert rel(got.last_representation, want['last_representation']) < 2e-2, (tag, rel(got.last_representation, want['last_representation']))
-    # gradients of the 101-token image student (and the text student next to it) against the oracle's, on a SMOOTH objective
-    # (out_cos): out_l1's sign(s - t) gradient flips under bf16 forward noise at B = 3 and would mask the backward's own error
-    from distillclip_amd.model import LossCalculator
-    for p in m.student.parameters():
-        p.grad = None
-    for v in list(sdi.values()) + list(sdt.values()):
-        v.grad = None
-    so, to = m.forward([image.cuda(), text.cuda()])
-    l2, _ = LossCalculator(['out_cos'])(so, to, 'all')
-    l2.backward()
-    oi, ot = oracle.student_image_forward(sdi, image, 24), oracle.student_text_forward(sdt, text, 12)
-    ol2, _ = oracle.LossOracle(['out_cos'])(oracle.clip_forward(oi, ot), oracle.clip_forward(ti, tt), 'all')
-    ol2.backward()
-    assert abs(l2.item() - ol2.item()) <= 2e-2 * abs(ol2.item())
-    named_i, named_t = dict(si.named_parameters()), dict(st.named_parameters())
-    errs = {}
-    for n in ('head.weight', 'pos_embed', 'patch_embed.proj.weight', 'blocks.2.block.mlp.fc1.weight', 'blocks.0.block.attn.qkv.weight',
-              'blocks.1.block.attn.proj.weight'):
-        errs['image.' + n] = rel(named_i[n].grad, sdi[n].grad)
-    for n in ('head.weight', 'blocks.0.block.mlp.fc2.weight', 'blocks.1.block.attn.qkv.weight'):
-        errs['text.' + n] = rel(named_t[n].grad, sdt[n].grad)
-    print('336 px gradient rel-L2 vs oracle', {k: round(v, 4) for k, v in errs.items()})
-    assert max(errs.values()) < 3e-2, errs             # measured <= 1.3e-2
+    # (the gradient of every parameter of both 101- / 77-token students is held to the reference's own run below:
+    #  test_l_clip_336px_real_shapes_vs_reference_golden)
 
 
 # ---- round 5: the same three configurations against the REFERENCE's own runs at real shapes (tests/golden/real_b4_{image1,textc,336}.npz,

@@ -504,6 +504,46 @@ def test_real_shapes_b4_backward_vs_rounding_matched_oracle():
     assert not bad, bad
 
 
+def test_c_abi_backward_is_self_contained_on_a_repeated_or_foreign_call(tiny):
+    """dclip_encoder_backward starts from a residual-stream gradient accumulator that the TRAINING FORWARD leaves cleared (the fills run beside
+    the other towers instead of on the critical path).  A caller outside the Python wrapper may call the backward twice on one forward
+    (several d_out: gradient checks), retry it, or use another workspace in between; round 4 then accumulated onto stale residual gradients
+    and returned wrong parameter gradients with rc = 0.  The handle now remembers which workspace its last training forward prepared and the
+    backward clears the seeds itself when it does not find its workspace there (include/dclip.h, dclip_encoder_backward): every variant below
+    returns the gradients of a fresh forward + backward."""
+    s_img, s_txt, _, _ = _tiny_modules()
+    image = torch.from_numpy(tiny['image']).cuda()
+    text = torch.from_numpy(tiny['text']).cuda()
+    for enc, x in ((s_img, image), (s_txt, text)):
+        tw = enc._tower
+        gen = torch.Generator().manual_seed(5)
+
+        def grads_of(d):
+            tw.flat_grad.zero_()
+            tw.backward(xin, d)
+            torch.cuda.synchronize()
+            return tw.flat_grad.clone()
+
+        out, xin, _, _ = tw.forward(x, training=True)
+        d1 = torch.randn(out.shape, generator=gen).cuda()
+        d2 = torch.randn(out.shape, generator=gen).cuda()
+        g1 = grads_of(d1)                                   # the ordinary call: consumes the forward's cleared seeds
+        tw._saved_batch = x.shape[0]                        # (the Python wrapper refuses a second backward; the C ABI must cope with it)
+        g2 = grads_of(d2)                                   # second backward on the same forward, another d_out
+        tw._saved_batch = x.shape[0]
+        g1_again = grads_of(d1)                             # ... and the first one repeated
+        # reference: each d_out on a forward of its own
+        tw.forward(x, training=True)
+        r1 = grads_of(d1)
+        tw.forward(x, training=True)
+        r2 = grads_of(d2)
+        scale = r1.abs().max().item()
+        for got, want, tag in ((g1, r1, 'first'), (g2, r2, 'second backward, other d_out'), (g1_again, r1, 'third backward, first d_out again')):
+            err = (got - want).abs().max().item()
+            assert err <= 2e-5 * scale, (type(enc).__name__, tag, err, scale)      # (f32 atomics of the small wgrads / column sums: order noise only)
+        assert (g2 - r1).abs().max().item() > 1e-2 * scale  # the two d_out really give different gradients
+
+
 def test_teacher_text_prefix_is_exact():
     """causal teacher text tower on the prefix that holds every EOT == on all 77 positions (the EOT row cannot see later tokens)"""
     from distillclip_amd.model.component import TextEncoder
@@ -541,7 +581,8 @@ def test_unfused_score_stage_path_matches_the_same_goldens():
         pytest.skip('already inside a child test process')
     torch.cuda.synchronize()
     env = dict(os.environ, DCLIP_ATTN_MIX='0', DCLIP_TEST_CHILD='1')
-    sel = 'tiny_forward_vs_reference_golden or tiny_dual_training_step or tiny_backward_vs_rounding_matched or real_shapes_b4'
+    # (tiny configuration: forward, training step, backward; real shapes: the every-parameter gradient golden and the matched oracle)
+    sel = 'tiny_forward_vs_reference_golden or tiny_dual_training_step or tiny_backward_vs_rounding_matched or real_shapes_b4_every or real_shapes_b4_backward'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', sel, '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
