@@ -4,14 +4,17 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from distillclip_amd import ops
-shapes = [(25600, 768, 3072, 'res'), (25600, 768, 768, 'res'), (25600, 2304, 768, 'bf16'), (25600, 3072, 768, 'qgelu'),
+shapes = [(25600, 768, 768, 'res16'), (25600, 768, 3072, 'res16'), (39424, 512, 512, 'res16'), (39424, 512, 2048, 'res16'),
+          (25600, 768, 3072, 'res'), (25600, 768, 768, 'res'), (25600, 2304, 768, 'bf16'), (25600, 3072, 768, 'qgelu'),
           (39424, 512, 2048, 'res'), (39424, 512, 512, 'res'), (39424, 1536, 512, 'bf16'), (39424, 2048, 512, 'qgelu'),
           (25600, 768, 3072, 'bf16'), (25600, 768, 2304, 'bf16'), (39424, 768, 3072, 'res'), (39424, 3072, 768, 'bf16')]
 for M, N, K, kind in shapes:
     a = torch.randn(M, K, device='cuda').bfloat16(); b = (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
     bias = torch.randn(N, device='cuda'); res = torch.randn(M, N, device='cuda'); out = torch.empty(M, N, device='cuda')
+    res16 = res.to(torch.float16)           # the frozen teacher's fp16 residual stream, in place
     def run():
         if kind == 'res': ops.gemm_nt(a, b, bias=bias, residual=res, out=out)
+        elif kind == 'res16': ops.gemm_nt(a, b, bias=bias, residual=res16, out=res16)
         elif kind == 'qgelu': ops.gemm_nt(a, b, bias=bias, act='quickgelu')
         else: ops.gemm_nt(a, b)
     for _ in range(5): run()
