@@ -1,6 +1,8 @@
 // Tower-level runtime: one C call = the whole stream-ordered launch sequence of an encoder tower.
 //
-//   teacher (frozen CLIP):  reference model/component/_common.py:188-221 (VisionTransformer.forward),
+//   CLIP tower (kind 0 frozen teacher / kind 2 trainable: the plain ImageEncoder / TextEncoder in the student role, reference
+//                           image_encoder.py:23-25,54-59, text_encoder.py:45-47,75-80):
+//                           reference model/component/_common.py:188-221 (VisionTransformer.forward),
 //                           model/component/text_encoder.py:62-92 (TextEncoder.encode_text)
 //   student (weight-shared MiniViT blocks): reference model/component/weight_share_model.py:336-372, :482-512
 //                           (forward_features), :199-218 (RepeatedMiniBlock), :179-185 (MiniBlock), :88-140 (MiniAttention)
@@ -44,7 +46,8 @@ enum { P_PER_TBLOCK = 12, P_PER_SBLOCK = 8, P_PER_SREPEAT = 6 };
 struct Plan {
     dclip_encoder_cfg c;
     int D, H, hd, N, Np, F, E, L, R, K;        // K = patch GEMM contraction (image)
-    bool student, image, compressed;
+    bool student, image, compressed;           // student = the weight-shared MiniViT architecture (kind 1)
+    bool train;                                // the tower has a backward (kind 1, 2): transposed weights cached, f32 residual stream
     // parameter indices
     int p_embed0;                              // first embedding parameter
     int p_blocks;                              // first block parameter
@@ -60,9 +63,9 @@ int64_t wtake(int64_t& off, int64_t n) { int64_t o = off; off += (n + 127) & ~(i
 
 bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
     p.c = c;
-    p.student = c.kind == 1; p.image = c.modality == 0;
+    p.student = c.kind == 1; p.train = c.kind != 0; p.image = c.modality == 0;
     p.D = c.width; p.H = c.heads; p.N = c.tokens; p.F = c.mlp_dim; p.E = c.out_dim; p.L = c.layers; p.R = c.repeats;
-    if (c.kind < 0 || c.kind > 1 || c.modality < 0 || c.modality > 1) { dclip_set_error("encoder: bad kind/modality"); return false; }
+    if (c.kind < 0 || c.kind > 2 || c.modality < 0 || c.modality > 1) { dclip_set_error("encoder: bad kind/modality"); return false; }
     if (p.D <= 0 || p.H <= 0 || p.D % p.H) { dclip_set_error("encoder: width %d not divisible by heads %d", p.D, p.H); return false; }
     p.hd = p.D / p.H;
     if (p.hd != 32 && p.hd != 64) { dclip_set_error("encoder: head dim %d unsupported (32 or 64)", p.hd); return false; }
@@ -81,6 +84,7 @@ bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
     } else {
         if (c.vocab <= 0) { dclip_set_error("encoder: vocab required for text"); return false; }
         if (p.compressed && c.embed_rank % 64) { dclip_set_error("encoder: embed_rank must be a multiple of 64"); return false; }
+        if (p.compressed && !p.student) { dclip_set_error("encoder: a compressed token embedding exists for the weight-shared student only (kind 1)"); return false; }
     }
     if (p.student && c.head_mix && p.H != 2 && p.H != 4 && p.H != 8 && p.H != 12 && p.H != 24) {
         dclip_set_error("encoder: head count %d unsupported by the head-mixing kernels", p.H); return false;
@@ -102,14 +106,14 @@ bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
     for (int l = 0; l < p.L; ++l) {
         auto& b = p.bw[l];
         b.qkv = wtake(off, 3 * D * D); b.proj = wtake(off, D * D); b.fc1 = wtake(off, F * D); b.fc2 = wtake(off, D * F);
-        if (p.student) { b.qkv_t = wtake(off, 3 * D * D); b.proj_t = wtake(off, D * D); b.fc1_t = wtake(off, F * D); b.fc2_t = wtake(off, D * F); }
+        if (p.train) { b.qkv_t = wtake(off, 3 * D * D); b.proj_t = wtake(off, D * D); b.fc1_t = wtake(off, F * D); b.fc2_t = wtake(off, D * F); }
         else b.qkv_t = b.proj_t = b.fc1_t = b.fc2_t = -1;
     }
     p.w_embed = p.w_embed_t = -1;
     if (p.image) p.w_embed = wtake(off, D * p.K);
     else if (p.compressed) { p.w_embed = wtake(off, D * c.embed_rank); p.w_embed_t = wtake(off, D * c.embed_rank); }
-    p.w_head = wtake(off, E * D);                                 // [E, D] (teacher: proj^T)
-    p.w_head_t = p.student ? wtake(off, E * D) : -1;              // [D, E]
+    p.w_head = wtake(off, E * D);                                 // [E, D] (CLIP towers: proj^T)
+    p.w_head_t = p.train ? wtake(off, E * D) : -1;                // [D, E]
     p.w_total = off;
     return true;
 }
@@ -138,7 +142,9 @@ struct Work {
     float *meanf, *rstdf;                  // final LN stats [B]
     bf16_t* hf;                            // [B, D]
     // temporaries
-    void* x0;                              // teacher image pre-ln_pre tokens (f16)
+    void* x0;                              // CLIP image tower: pre-ln_pre tokens (f16 frozen, f32 trainable)
+    float *mean0, *rstd0;                  // ln_pre statistics (trainable CLIP image tower)
+    float* G0;                             // gradient of the pre-ln_pre tokens (trainable CLIP image tower)
     float* G; bf16_t* Gb;                  // residual-stream gradient
     // gradients that are wgrad operands keep one slot per repeat: the R executions of a weight-shared block feed ONE
     // wgrad GEMM over R * M rows (half the launches and half the f32 atomic traffic at R = 2)
@@ -157,13 +163,13 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     const int64_t Npad = (N + 7) & ~(int64_t)7;
     const int64_t M = B * N, D = p.D, F = p.F, SN = B * p.H * N * Npad;
     const int nex = p.L * p.R;
-    const bool save = p.student && training;
+    const bool save = p.train && training;
     w.X.assign(nex + 1, nullptr);
     w.ex.assign(nex, ExecSave{});
     // teacher / inference: a single ping-pong set reused by every block
     ExecSave shared{};
     void* xs = nullptr;
-    w.h16 = !p.student;
+    w.h16 = !p.train;
     if (!save) {
         xs = w.h16 ? (void*)b.take<_Float16>(M * D) : (void*)b.take<float>(M * D);
         shared.x_mid = xs;   // in-place residual stream
@@ -199,7 +205,9 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     w.pick = b.take<int32_t>(B);
     w.meanf = b.take<float>(B); w.rstdf = b.take<float>(B);
     w.hf = b.take<bf16_t>(B * D);
-    w.x0 = (!p.student && p.image) ? (void*)b.take<_Float16>(M * D) : nullptr;
+    w.x0 = (!p.student && p.image) ? (w.h16 ? (void*)b.take<_Float16>(M * D) : (void*)b.take<float>(M * D)) : nullptr;
+    const bool pre = save && !p.student && p.image;
+    w.mean0 = pre ? b.take<float>(M) : nullptr; w.rstd0 = pre ? b.take<float>(M) : nullptr; w.G0 = pre ? b.take<float>(M * D) : nullptr;
     if (save) {
         w.G = b.take<float>(M * D); w.Gb = b.take<bf16_t>(M * D);
         w.gb_f2 = b.take<bf16_t>(p.R * M * D); w.gb_pr = b.take<bf16_t>(p.R * M * D);
@@ -310,9 +318,19 @@ inline SB sblock(const Plan& p, int l) {
     return SB{b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6, b + 7};
 }
 struct SR { int n1w, n1b, n2w, n2b, cl, cw; };
+// one block execution's parameters under the names the backward uses, for both architectures (CLIP: ln_1/2, in_proj, out_proj, c_fc, c_proj)
+struct BX { int n1w, n1b, n2w, n2b, qkvw, qkvb, prw, prb, f1w, f1b, f2w, f2b, cl, cw; };
 inline SR srepeat(const Plan& p, int l, int r) {
     const int b = p.p_blocks + l * (P_PER_SBLOCK + p.R * P_PER_SREPEAT) + P_PER_SBLOCK + r * P_PER_SREPEAT;
     return SR{b, b + 1, b + 2, b + 3, b + 4, b + 5};
+}
+inline BX bexec(const Plan& p, int l, int r) {
+    if (p.student) {
+        const SB s = sblock(p, l); const SR q = srepeat(p, l, r);
+        return BX{q.n1w, q.n1b, q.n2w, q.n2b, s.qkvw, s.qkvb, s.prw, s.prb, s.f1w, s.f1b, s.f2w, s.f2b, q.cl, q.cw};
+    }
+    const TB t = tblock(p, l);
+    return BX{t.ln1w, t.ln1b, t.ln2w, t.ln2b, t.inw, t.inb, t.outw, t.outb, t.fcw, t.fcb, t.prw, t.prb, -1, -1};
 }
 }  // namespace
 
@@ -338,7 +356,7 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
     if (p.image) job(PF(params, 0), at(p.w_embed), nullptr, D, p.K);                          // conv weight [D, C*p*p]
     else if (p.compressed) job(PF(params, 1), at(p.w_embed), at(p.w_embed_t), D, p.c.embed_rank);
     if (p.student) job(PF(params, p.p_final + 2), at(p.w_head), at(p.w_head_t), E, D);
-    else job(PF(params, p.p_final + 2), nullptr, at(p.w_head), D, E);                         // proj [D,E] -> [E,D]
+    else job(PF(params, p.p_final + 2), at(p.w_head_t), at(p.w_head), D, E);                  // proj [D,E] -> [E,D] (+ as it is: the dgrad operand of a trainable tower)
     for (size_t i = 0; i < src.size(); ++i) DCLIP_REQUIRE(src[i], "dclip_encoder_prepare: parameter %zu missing", i);
     return dclip_cast_transpose_bf16_multi(src.data(), wb.data(), wt.data(), rr.data(), cc.data(), (int64_t)src.size(), st);
 }
@@ -369,10 +387,10 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
     DCLIP_REQUIRE(B > 0, "dclip_encoder_forward: empty batch");
     const Plan& p = e->p;
     DCLIP_REQUIRE(!ext_patches || (p.image && ((uintptr_t)ext_patches % 16) == 0), "dclip_encoder_forward_patches: image towers only, 16-byte aligned rows");
-    DCLIP_REQUIRE(!training || p.student, "dclip_encoder_forward: the teacher tower is inference-only");
+    DCLIP_REQUIRE(!training || p.train, "dclip_encoder_forward: the frozen teacher tower (kind 0) is inference-only");
     // tokens_eff: causal text teacher only.  Positions after the longest caption's EOT cannot influence any EOT row (causal
     // attention; LN / MLP are per token), so the tower may run on the first tokens_eff positions with identical output.
-    DCLIP_REQUIRE(tokens_eff == 0 || (!p.student && !p.image && p.c.causal && tokens_eff > 0 && tokens_eff <= p.N && !rep_out && !emb_out),
+    DCLIP_REQUIRE(tokens_eff == 0 || (!p.train && !p.image && p.c.causal && tokens_eff > 0 && tokens_eff <= p.N && !rep_out && !emb_out),
                   "dclip_encoder_forward: tokens_eff is only valid for the causal text teacher without hidden-state export");
     Work w;
     layout(p, B, training != 0, workspace, w, tokens_eff);
@@ -392,8 +410,9 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
             CK(gemm(patches, p.K, W + p.w_embed, p.K, w.X[0], D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, 1, N, w.tok_table, st));
         } else {           // params: 0 conv1 w, 1 class_embedding, 2 positional_embedding, 3 ln_pre w, 4 ln_pre b
             CK(dclip_token_table(PF(params, 2), PF(params, 1), nullptr, w.tok_table, N, D, st));
-            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, DCLIP_OUT_F16, N, w.tok_table, st));
-            CK(ln_stream(true, w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, DCLIP_OUT_F16, nullptr, nullptr, M, D, st));
+            const int sdt0 = w.h16 ? DCLIP_OUT_F16 : DCLIP_OUT_F32;
+            CK(gemm(patches, p.K, W + p.w_embed, p.K, w.x0, D, M, D, p.K, nullptr, 0, nullptr, nullptr, nullptr, 0, sdt0, N, w.tok_table, st));
+            CK(ln_stream(w.h16, w.x0, D, nullptr, PF(params, 3), PF(params, 4), w.X[0], D, sdt0, w.mean0, w.rstd0, M, D, st));
         }
     } else if (p.compressed) {   // params: 0 table [V,rank], 1 linear w [D,rank], 2 linear b, 3 pos
         CK(dclip_embed_gather((const int64_t*)input, p.N, PF(params, 0), nullptr, w.patches, 0, M, N, p.c.embed_rank, st));
@@ -413,15 +432,11 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
         const auto& bw = p.bw[l];
         ExecSave& s = w.ex[ei];
         const float *n1w, *n1b, *n2w, *n2b, *bq, *bp, *b1, *b2, *wl = nullptr, *ww = nullptr;
-        if (p.student) {
-            SB sb = sblock(p, l); SR sr = srepeat(p, l, r);
-            n1w = PF(params, sr.n1w); n1b = PF(params, sr.n1b); n2w = PF(params, sr.n2w); n2b = PF(params, sr.n2b);
-            bq = PF(params, sb.qkvb); bp = PF(params, sb.prb); b1 = PF(params, sb.f1b); b2 = PF(params, sb.f2b);
-            if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
-        } else {
-            TB tb = tblock(p, l);
-            n1w = PF(params, tb.ln1w); n1b = PF(params, tb.ln1b); n2w = PF(params, tb.ln2w); n2b = PF(params, tb.ln2b);
-            bq = PF(params, tb.inb); bp = PF(params, tb.outb); b1 = PF(params, tb.fcb); b2 = PF(params, tb.prb);
+        {
+            const BX bx = bexec(p, l, r);
+            n1w = PF(params, bx.n1w); n1b = PF(params, bx.n1b); n2w = PF(params, bx.n2w); n2b = PF(params, bx.n2b);
+            bq = PF(params, bx.qkvb); bp = PF(params, bx.prb); b1 = PF(params, bx.f1b); b2 = PF(params, bx.f2b);
+            if (p.student && p.c.head_mix) { wl = PF(params, bx.cl); ww = PF(params, bx.cw); }
         }
         void* xin = w.X[ei];
         void* xout = w.X[ei + 1];
@@ -443,7 +458,7 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
         }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, sdt, 0, nullptr, st));
         CK(ln_stream(w.h16, s.x_mid, D, nullptr, n2w, n2b, s.h2, D, DCLIP_OUT_BF16, s.mean2, s.rstd2, M, D, st));
-        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : DCLIP_ACT_QUICKGELU, nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
+        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : (s.z ? DCLIP_ACT_QUICKGELU_SAVE : DCLIP_ACT_QUICKGELU), nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
         CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, sdt, 0, nullptr, st));
         // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
         if (rep_out && rep_out[ei]) CK(export_stream(w.h16, xout, rep_out[ei], M * D, st));
@@ -487,7 +502,7 @@ extern "C" int dclip_encoder_last_layer_output(const dclip_encoder* e, int64_t B
     DCLIP_REQUIRE(e && params && wcache && workspace && scratch && out, "dclip_encoder_last_layer_output: null argument");
     DCLIP_REQUIRE(B > 0, "dclip_encoder_last_layer_output: empty batch");
     const Plan& p = e->p;
-    DCLIP_REQUIRE(!training || p.student, "dclip_encoder_last_layer_output: the teacher tower is inference-only");
+    DCLIP_REQUIRE(!training || p.train, "dclip_encoder_last_layer_output: the frozen teacher tower (kind 0) is inference-only");
     Work w;
     layout(p, B, training != 0, workspace, w);
     DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_last_layer_output: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
@@ -506,7 +521,7 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
     DCLIP_REQUIRE(e && (input || ext_patches) && params && grads && wcache && workspace && d_last_representation, "dclip_encoder_backward: null argument");
     const Plan& p = e->p;
     DCLIP_REQUIRE(!ext_patches || p.image, "dclip_encoder_backward_patches: image towers only");
-    DCLIP_REQUIRE(p.student, "dclip_encoder_backward: only the student tower trains");
+    DCLIP_REQUIRE(p.train, "dclip_encoder_backward: the frozen teacher tower (kind 0) has no backward");
     Work w;
     layout(p, B, true, workspace, w);
     DCLIP_REQUIRE(ws_bytes >= w.bytes, "dclip_encoder_backward: workspace too small");
@@ -526,15 +541,19 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
     // ---- head + final norm -----------------------------------------------------------------------------------
     const int f = p.p_final;
     CK(dclip_cast_bf16(d_last_representation, w.dout, B * E, st));
-    if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, w.tn_ws, w.tn_ws_bytes, st));
-    if (GR(f + 3)) CK(dclip_colsum_acc(w.dout, E, GR(f + 3), B, E, st));
+    if (p.student) {         // head = nn.Linear: weight [E, D], bias
+        if (GR(f + 2)) CK(dclip_gemm_tn_acc(w.dout, E, w.hf, D, GR(f + 2), D, B, E, D, 1, w.tn_ws, w.tn_ws_bytes, st));
+        if (GR(f + 3)) CK(dclip_colsum_acc(w.dout, E, GR(f + 3), B, E, st));
+    } else if (GR(f + 2)) {  // x @ proj: proj [D, E], no bias (reference _common.py:213, text_encoder.py:72)
+        CK(dclip_gemm_tn_acc(w.hf, D, w.dout, E, GR(f + 2), E, B, D, E, 1, w.tn_ws, w.tn_ws_bytes, st));
+    }
     CK(gemm(w.dout, E, W + p.w_head_t, E, w.dh, D, B, D, E, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
     // every LayerNorm backward also emits the column sums of the updated residual gradient = the bias gradient of the
     // linear that wrote into that residual stream (fc2 of the previous execution / attn.proj of this one)
     const int R = p.R;
     bf16_t* gb_last = w.gb_f2 + (int64_t)(R - 1) * M * D;            // fc2 of the last execution reads slot R - 1
     CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)w.X[nex], D, w.pick, PF(params, f), w.meanf, w.rstdf, w.G, D, gb_last, D, GR(f), GR(f + 1),
-                           GR(sblock(p, (nex - 1) / p.R).f2b), B, D, st));
+                           GR(bexec(p, (nex - 1) / p.R, 0).f2b), B, D, st));
     // gradient bucket 0 (final norm + head) is complete: every launch that writes it is enqueued on `st`
     if (on_bucket) on_bucket(cb_user, 0);
 
@@ -543,9 +562,9 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
         const int l = ei / p.R, r = ei % p.R;
         const auto& bw = p.bw[l];
         const ExecSave& s = w.ex[ei];
-        const SB sb = sblock(p, l); const SR sr = srepeat(p, l, r);
+        const BX bx = bexec(p, l, r);
         const float *wl = nullptr, *ww = nullptr;
-        if (p.c.head_mix) { wl = PF(params, sr.cl); ww = PF(params, sr.cw); }
+        if (p.student && p.c.head_mix) { wl = PF(params, bx.cl); ww = PF(params, bx.cw); }
         // this execution's slots; a block's wgrads run once, after its first execution's gradients are there (r == 0)
         bf16_t* gb_f2 = w.gb_f2 + (int64_t)r * M * D;
         bf16_t* gb_pr = w.gb_pr + (int64_t)r * M * D;
@@ -554,48 +573,59 @@ static int encoder_backward_impl(const dclip_encoder* e, const void* input, cons
         const int64_t MR = (int64_t)R * M;
         const ExecSave& s0 = w.ex[ei - r];                               // execution r = 0 of this block: base of the [R][M, .] operands
         // gradient arriving directly at this execution's output (feature-MSE terms): G += d_rep[ei], refresh the bf16 copy
-        if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], gb_f2, M * D, GR(sb.f2b), D, st));
+        if (d_rep && d_rep[ei]) CK(dclip_axpy_f32(w.G, d_rep[ei], gb_f2, M * D, GR(bx.f2b), D, st));
         // MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         CK(dclip_gemm_nt(gb_f2, D, W + bw.fc2_t, D, dbig, F, M, F, D, 1.f, nullptr, DCLIP_ACT_MULAUX, s.z, nullptr, nullptr, 0, 0, 0, nullptr,
-                         GR(sb.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
-        if (r == 0 && GR(sb.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(sb.f2w), F, MR, D, F, wsplits(MR, D, F), w.tn_ws, w.tn_ws_bytes, st));
-        if (r == 0 && GR(sb.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(sb.f1w), D, MR, F, D, wsplits(MR, F, D), w.tn_ws, w.tn_ws_bytes, st));
+                         GR(bx.f1b), st));                                        // dz = (G W2) o gelu'(z) ; db1 += colsum(dz)
+        if (r == 0 && GR(bx.f2w)) CK(dclip_gemm_tn_acc(w.gb_f2, D, s0.u, F, GR(bx.f2w), F, MR, D, F, wsplits(MR, D, F), w.tn_ws, w.tn_ws_bytes, st));
+        if (r == 0 && GR(bx.f1w)) CK(dclip_gemm_tn_acc(w.dbig, F, s0.h2, D, GR(bx.f1w), D, MR, F, D, wsplits(MR, F, D), w.tn_ws, w.tn_ws_bytes, st));
         CK(gemm(dbig, F, W + bw.fc1_t, F, w.dh, D, M, D, F, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)s.x_mid, D, nullptr, PF(params, sr.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(sr.n2w), GR(sr.n2b),
-                               GR(sb.prb), M, D, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)s.x_mid, D, nullptr, PF(params, bx.n2w), s.mean2, s.rstd2, w.G, D, gb_pr, D, GR(bx.n2w), GR(bx.n2b),
+                               GR(bx.prb), M, D, st));
         // attention: x_mid = x_in + proj(attn(LN1(x_in)))
-        if (r == 0 && GR(sb.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(sb.prw), D, MR, D, D, wsplits(MR, D, D), w.tn_ws, w.tn_ws_bytes, st));
+        if (r == 0 && GR(bx.prw)) CK(dclip_gemm_tn_acc(w.gb_pr, D, s0.ctx, D, GR(bx.prw), D, MR, D, D, wsplits(MR, D, D), w.tn_ws, w.tn_ws_bytes, st));
         bf16_t* dctx = w.dh;
         CK(gemm(gb_pr, D, W + bw.proj_t, D, dctx, D, M, D, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         const int blk = (wl && mix_attn(p, N)) ? 1 : 0;        // R and dS of the register-resident score stage are quad-blocked
         CK(dclip_attn_tn(s.Rm, dctx, D, dqkv + 2 * D, 3 * D, B, H, N, Np, hd, 1.f, blk, st));                    // dV = R^T dO
         if (wl && mix_attn(p, N)) {
-            float* gl = GR(sr.cl) ? GR(sr.cl) : w.wg_dummy;
-            float* gw = GR(sr.cw) ? GR(sr.cw) : w.wg_dummy + H * H;
+            float* gl = GR(bx.cl) ? GR(bx.cl) : w.wg_dummy;
+            float* gw = GR(bx.cw) ? GR(bx.cw) : w.wg_dummy + H * H;
             CK(dclip_attn_mix_bwd(s.qkv, 3 * D, dctx, D, wl, ww, s.stats, w.dS, gl, gw, w.mix_ws, w.mix_ws_bytes, B, H, N, Np, hd, scale, st));
         } else {
             CK(dclip_attn_nt(dctx, D, s.qkv + 2 * D, 3 * D, w.dR, 0, B, H, N, Np, hd, 1.f, st));               // dR = dO V^T
-            CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, 0, wl, ww, w.dS, wl ? GR(sr.cl) : nullptr,
-                                      wl ? GR(sr.cw) : nullptr, B, H, N, Np, st));
+            CK(dclip_attn_softmax_bwd(w.dR, s.P, s.S, 0, wl, ww, w.dS, wl ? GR(bx.cl) : nullptr,
+                                      wl ? GR(bx.cw) : nullptr, B, H, N, Np, st));
         }
         CK(dclip_attn_nn(w.dS, s.qkv + D, 3 * D, dqkv, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dQ = dS K
         CK(dclip_attn_tn(w.dS, s.qkv, 3 * D, dqkv + D, 3 * D, B, H, N, Np, hd, scale, blk, st));                 // dK = dS^T Q
-        if (r == 0 && GR(sb.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(sb.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), w.tn_ws, w.tn_ws_bytes, st));
-        if (r == 0 && params[sb.qkvb] && GR(sb.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(sb.qkvb), MR, 3 * D, st));
+        if (r == 0 && GR(bx.qkvw)) CK(dclip_gemm_tn_acc(w.dqkv, 3 * D, s0.h1, D, GR(bx.qkvw), D, MR, 3 * D, D, wsplits(MR, 3 * D, D), w.tn_ws, w.tn_ws_bytes, st));
+        if (r == 0 && params[bx.qkvb] && GR(bx.qkvb)) CK(dclip_colsum_acc(w.dqkv, 3 * D, GR(bx.qkvb), MR, 3 * D, st));
         CK(gemm(dqkv, 3 * D, W + bw.qkv_t, 3 * D, w.dh, D, M, D, 3 * D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         // the bf16 residual gradient leaving this execution is the fc2 operand of the previous one (slot of its repeat index)
         bf16_t* gb_next = ei > 0 ? w.gb_f2 + (int64_t)((ei - 1) % R) * M * D : w.Gb;
-        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)w.X[ei], D, nullptr, PF(params, sr.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(sr.n1w), GR(sr.n1b),
-                               ei > 0 ? GR(sblock(p, (ei - 1) / p.R).f2b) : nullptr, M, D, st));
+        CK(dclip_layernorm_bwd(w.dh, D, 0, (const float*)w.X[ei], D, nullptr, PF(params, bx.n1w), s.mean1, s.rstd1, w.G, D, gb_next, D, GR(bx.n1w), GR(bx.n1b),
+                               ei > 0 ? GR(bexec(p, (ei - 1) / p.R, 0).f2b) : nullptr, M, D, st));
         // block l's gradients (shared weights: both repeats; its fc2 bias also collects from block l + 1's first LayerNorm
         // backward, which ran earlier) are complete after its first execution's backward: bucket 1 + (L - 1 - l)
         if (r == 0 && on_bucket) on_bucket(cb_user, 1 + (p.L - 1 - l));
     }
 
     // ---- embedding ---------------------------------------------------------------------------------------------
-    if (d_emb) CK(dclip_axpy_f32(w.G, d_emb, w.Gb, M * D, nullptr, D, st));
+    const bool clip_image = !p.student && p.image;       // the exported embedding of a CLIP image tower is taken BEFORE ln_pre (_common.py:204-208)
+    if (d_emb && !clip_image) CK(dclip_axpy_f32(w.G, d_emb, w.Gb, M * D, nullptr, D, st));
     if (hipMemsetAsync(w.tok_sum, 0, (size_t)N * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
-    if (p.image) {           // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
+    if (clip_image) {        // grads: 0 conv1 w, 1 class_embedding, 2 positional_embedding, 3 ln_pre w, 4 ln_pre b
+        // x = ln_pre(x0), no bypass: the gradient of x0 is LN'(G) alone, accumulated into a cleared buffer
+        if (hipMemsetAsync(w.G0, 0, (size_t)M * D * 4, hs) != hipSuccess) { dclip_set_error("dclip_encoder_backward: memset failed"); return DCLIP_ELAUNCH; }
+        CK(dclip_layernorm_bwd(w.G, D, 1, (const float*)w.x0, D, nullptr, PF(params, 3), w.mean0, w.rstd0, w.G0, D, w.Gb, D, GR(3), GR(4), nullptr, M, D, st));
+        if (d_emb) CK(dclip_axpy_f32(w.G0, d_emb, w.Gb, M * D, nullptr, D, st));
+        if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, ext_patches ? ext_patches : w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), w.tn_ws, w.tn_ws_bytes, st));
+        if (GR(1) || GR(2)) {
+            CK(dclip_batch_sum_acc(w.G0, w.tok_sum, B, N, D, st));
+            CK(dclip_token_table_bwd(w.tok_sum, GR(2), GR(1), nullptr, N, D, 1, st));
+        }
+    } else if (p.image) {    // grads: 0 conv w, 1 conv b, 2 cls, 3 pos
         if (GR(0)) CK(dclip_gemm_tn_acc(w.Gb, D, ext_patches ? ext_patches : w.patches, p.K, GR(0), p.K, M, D, p.K, wsplits(M, D, p.K), w.tn_ws, w.tn_ws_bytes, st));
         if (GR(1) || GR(2) || GR(3)) {
             CK(dclip_batch_sum_acc(w.G, w.tok_sum, B, N, D, st));

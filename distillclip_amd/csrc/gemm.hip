@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         }
     };
     // (kernel arguments: the tests below are scalar, the whole workgroup takes one path)
-    const bool lean = p.row_group == 0 && (ACT == 5 ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT != 0 ? p.residual != nullptr : p.residual == nullptr);
+    const bool lean = p.row_group == 0 && ((ACT == 5 || ACT == 6) ? p.aux_out != nullptr : p.aux_out == nullptr) && (OUT != 0 ? p.residual != nullptr : p.residual == nullptr);
     if constexpr (OUT != 0) {
         if (lean) run_units(std::integral_constant<int, 3>{});
         else run_units(std::integral_constant<int, 0>{});
@@ -1082,7 +1082,9 @@ int launch_nt(GemmNT p, int out, hipStream_t st) {
     // OUT = 2 (f16 output + f16 in-place residual: the frozen teacher's residual stream) exists for the plain epilogue only
     if constexpr (ACT != 0) { if (out == 2) { dclip_set_error("dclip_gemm_nt: f16 output needs act = DCLIP_ACT_NONE"); return DCLIP_EINVAL; } }
     const bool out_f32 = out == 1;
-    if (use_256(p) && !(out != 0 && p.colsum)) {      // (the 256- / 320-row kernels keep column sums only with bf16 output)
+    // (the 256- / 320-row kernels keep column sums only with bf16 output, and an activation only with bf16 output: the step's activated
+    //  GEMMs all store bf16 — an f32 store after an activation is served by the 128^2 kernel, 15 instantiations less in the library)
+    if (use_256(p) && !(out != 0 && p.colsum) && (ACT == 0 || out == 0)) {
         int tm = (p.M + 255) / 256;
         const int tn = (p.N + 255) / 256;
         // tile height: 192, 256 or 320 rows (MI = 6, 8, 10), whichever needs the fewest rounds x cycles per tile on 256 CUs (a tie keeps
@@ -1128,20 +1130,20 @@ int launch_nt(GemmNT p, int out, hipStream_t st) {
         }
         if (mi == 10) {
             const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2) + 16;
-            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 10>), dim3(ntiles), dim3(512), lds320, st, p);
+            if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
             else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 10>), dim3(ntiles), dim3(512), lds320, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         if (mi == 6) {
             const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2) + 16;
-            if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 6>), dim3(ntiles), dim3(512), lds192, st, p);
+            if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
             else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 6>), dim3(ntiles), dim3(512), lds192, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         const size_t lds256 = 8 * HT + 16;
-        if (out_f32) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 1, 8>), dim3(ntiles), dim3(512), lds256, st, p);
+        if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
         else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
         else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 8>), dim3(ntiles), dim3(512), lds256, st, p);
         return dclip_check_launch("dclip_gemm_nt");
@@ -1180,7 +1182,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     DCLIP_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0, "dclip_gemm_nt: N and ldc must be multiples of 8 and C 16-byte aligned (N=%ld ldc=%ld)", (long)N, (long)ldc);
     DCLIP_REQUIRE(out_dtype >= 0 && out_dtype <= 2, "dclip_gemm_nt: bad output dtype %d (0 bf16, 1 f32, 2 f16)", out_dtype);
     DCLIP_REQUIRE(!residual || (ldr % (out_dtype == 2 ? 8 : 4) == 0 && ((uintptr_t)residual % 16) == 0), "dclip_gemm_nt: residual rows must be 16-byte aligned");
-    DCLIP_REQUIRE(act >= 0 && act <= 5, "dclip_gemm_nt: bad activation code %d", act);
+    DCLIP_REQUIRE(act >= 0 && act <= 6, "dclip_gemm_nt: bad activation code %d", act);
     DCLIP_REQUIRE(out_dtype != 2 || act == 0, "dclip_gemm_nt: f16 output needs act = DCLIP_ACT_NONE");
     DCLIP_REQUIRE((act != DCLIP_ACT_DGELU && act != DCLIP_ACT_MULAUX) || aux_in, "dclip_gemm_nt: DGELU / MULAUX need aux_in");
     DCLIP_REQUIRE(!aux_in || ((uintptr_t)aux_in % 16) == 0, "dclip_gemm_nt: aux_in must be 16-byte aligned");
@@ -1200,7 +1202,7 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     // algorithmic bytes of the call: both operands once, the output once, plus what the fused epilogue consumes / produces — the f32 residual
     // it adds (read), the saved pre-activation / derivative it multiplies by (aux_in) or stores (aux_out); round 3 counted operands + output only
     const int out_f32 = out_dtype == 1;
-    const double aux_b = (act == DCLIP_ACT_MULAUX || act == DCLIP_ACT_GELU_SAVE) ? 1.0 : 2.0;      // the saved gelu' is one byte per element
+    const double aux_b = (act == DCLIP_ACT_MULAUX || act == DCLIP_ACT_GELU_SAVE || act == DCLIP_ACT_QUICKGELU_SAVE) ? 1.0 : 2.0;      // the saved gelu' is one byte per element
     TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K,
                   2.0 * ((double)M * K + (double)N * K) + ((out_f32 ? 4.0 : 2.0) + (residual ? (out_dtype == 2 ? 2.0 : 4.0) : 0.0) + (aux_in ? aux_b : 0.0) + (aux_out ? aux_b : 0.0)) * (double)M * N,
                   stream, (int)M, (int)N, (int)K,
@@ -1211,7 +1213,8 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
         case 2: return launch_nt<2>(p, out_dtype, st);
         case 3: return launch_nt<3>(p, out_dtype, st);
         case 4: return launch_nt<4>(p, out_dtype, st);
-        default: return launch_nt<5>(p, out_dtype, st);
+        case 5: return launch_nt<5>(p, out_dtype, st);
+        default: return launch_nt<6>(p, out_dtype, st);
     }
 }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int64_t o, i
 
 // MODE 0: every optional operand is a run-time test (wave-uniform branches: four per 8-column unit, 80 per 320 x 256 tile and wave —
 // about 40 % of the issue slots of a plain bf16 epilogue, which is issue-bound).  MODE 1 / 2: the launch has no positional table, no
-// residual and no saved pre-activation (ACT 5 always saves its derivative), without / with bias-gradient column sums — the
+// residual and no saved pre-activation (ACT 5 / 6 always save their derivative), without / with bias-gradient column sums — the
 // combinations the step's bf16 GEMMs use; the tests are compiled out.
 template <int ACT, int OUT, int MODE = 0>
 __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, int64_t o, int64_t orr,
@@ -72,7 +72,7 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
         const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
     }
-    if (!LEAN && ACT != 5 && p.aux_out) {
+    if (!LEAN && ACT != 5 && ACT != 6 && p.aux_out) {
         bf16x8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = f2bf(v[e]);
@@ -103,6 +103,16 @@ __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], in
             float g;
             gelu_erf_both_f(v[e], g, dg[e]);
             v[e] = g;
+        }
+        if (LEAN || p.aux_out) *(uint2*)((uint8_t*)p.aux_out + o) = uint2{dg_pack4(dg[0], dg[1], dg[2], dg[3]), dg_pack4(dg[4], dg[5], dg[6], dg[7])};
+    }
+    if (ACT == 6) {      // QuickGELU of a trainable CLIP tower: x s(1.702 x) and its derivative s + 1.702 x s (1 - s), in [-0.1, 1.1]
+        float dg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+            dg[e] = fmaf(1.702f * v[e] * sg, 1.f - sg, sg);
+            v[e] *= sg;
         }
         if (LEAN || p.aux_out) *(uint2*)((uint8_t*)p.aux_out + o) = uint2{dg_pack4(dg[0], dg[1], dg[2], dg[3]), dg_pack4(dg[4], dg[5], dg[6], dg[7])};
     }

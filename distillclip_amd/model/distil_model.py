@@ -13,6 +13,7 @@ from torch import nn
 from ._loss import LossCalculator
 from .utils import teacher_load
 from .component.weight_share_model import RepeatVisionTransformer
+from .component.image_encoder import ImageEncoder
 from .component._tower import shared_image_patches
 from ..optim import FusedAdamW, EpochCosineSchedule
 from ..parallel import GradSync
@@ -143,7 +144,8 @@ class DistillModel(nn.Module):
     def configure_optimizers(self):
         # reference :160-169: AdamW over every requires_grad parameter (one group) + cosine schedule stepped per epoch
         self.student._tower.materialize(next(self.student.parameters()).device)
-        opt = FusedAdamW([self.student._tower], lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
+        extras = getattr(self.student, 'extra_parameters', lambda: [])()       # a plain CLIP encoder's projection linears
+        opt = FusedAdamW([self.student._tower], lr=self.hparams.lr, weight_decay=self.hparams.weight_decay, extra_params=extras)
         sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
         self._ensure_sync()          # data-parallel run: shard plan over the same trainable set the optimizer was built with
         return [opt], [sched]
@@ -159,8 +161,18 @@ class DistillModel(nn.Module):
 
     def freeze_image_embedding(self):
         # reference :197-213
+        if isinstance(self.student, ImageEncoder):             # reference :211-219
+            freeze_key = ['visual.conv1.weight', 'visual.class_embedding', 'visual.positional_embedding']
+            sw, tw = self.student.state_dict(), self.teacher.state_dict()
+            for k in freeze_key:
+                sw[k] = tw[k]
+            self.student.load_state_dict(sw)
+            for n, p in self.student.named_parameters():
+                if n in freeze_key:
+                    p.requires_grad = False
+            return
         if not isinstance(self.student, RepeatVisionTransformer):
-            raise NotImplementedError('freeze_embed is implemented for RepeatVisionTransformer students')
+            return                                             # (the reference does nothing for other student classes)
         stu_keys = ['patch_embed.proj.weight', 'cls_token', 'pos_embed']
         tea_keys = ['visual.conv1.weight', 'visual.class_embedding', 'visual.positional_embedding']
         sw, tw = self.student.state_dict(), self.teacher.state_dict()

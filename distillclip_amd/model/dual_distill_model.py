@@ -16,6 +16,7 @@ from .utils import teacher_load
 from .component.clip_model import CLIPModel
 from .component.output import CLIPOutput
 from .component.weight_share_model import RepeatVisionTransformer
+from .component.image_encoder import ImageEncoder
 from .component._tower import shared_image_patches
 from .distil_model import _HParams
 from ..optim import FusedAdamW, EpochCosineSchedule
@@ -243,7 +244,9 @@ class DualDistillModel(nn.Module):
         dev = next(self.student.parameters()).device
         for tw in self.towers():
             tw.materialize(dev)
-        opt = FusedAdamW(self.towers(), lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
+        extras = [p for enc in (self.student.image_encoder, self.student.text_encoder)
+                  for p in getattr(enc, 'extra_parameters', lambda: [])()]     # plain CLIP encoders' projection linears
+        opt = FusedAdamW(self.towers(), lr=self.hparams.lr, weight_decay=self.hparams.weight_decay, extra_params=extras)
         sched = EpochCosineSchedule(opt, self.hparams.warm_steps, self.hparams.total_steps)
         self._ensure_sync()          # data-parallel run: shard plan over the same trainable set the optimizer was built with
         return [opt], [sched]
@@ -268,8 +271,18 @@ class DualDistillModel(nn.Module):
     def freeze_image_embedding(self):
         # reference :240-268: teacher patch / class / positional embeddings copied into the image student and frozen
         enc = self.student.image_encoder
+        if isinstance(enc, ImageEncoder):                      # reference :258-266: same keys on both sides
+            freeze_key = ['visual.conv1.weight', 'visual.class_embedding', 'visual.positional_embedding']
+            sw, tw = enc.state_dict(), self.teacher.state_dict()
+            for k in freeze_key:
+                sw[k] = tw['image_encoder.' + k]
+            enc.load_state_dict(sw)
+            for n, p in enc.named_parameters():
+                if n in freeze_key:
+                    p.requires_grad = False
+            return
         if not isinstance(enc, RepeatVisionTransformer):
-            raise NotImplementedError('freeze_embed is implemented for RepeatVisionTransformer students')
+            return                                             # (the reference does nothing for other student classes)
         keys = {'patch_embed.proj.weight': 'image_encoder.visual.conv1.weight',
                 'cls_token': 'image_encoder.visual.class_embedding', 'pos_embed': 'image_encoder.visual.positional_embedding'}
         sw, tw = enc.state_dict(), self.teacher.state_dict()

@@ -4,7 +4,7 @@ import torch
 
 from ._lib import lib
 
-ACT = {'none': 0, None: 0, 'quickgelu': 1, 'gelu': 2, 'dgelu': 3, 'mulaux': 4, 'gelu_save': 5}
+ACT = {'none': 0, None: 0, 'quickgelu': 1, 'gelu': 2, 'dgelu': 3, 'mulaux': 4, 'gelu_save': 5, 'quickgelu_save': 6}
 OUT_DTYPE = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}      # DCLIP_OUT_*
 # 8-bit fixed-point code of the saved gelu' (include/dclip.h: DCLIP_ACT_GELU_SAVE / DCLIP_ACT_MULAUX): value = DG_LO + q * DG_STEP
 DG_LO, DG_STEP = -0.13, 1.26 / 255.0
@@ -27,7 +27,7 @@ def _chk(*ts):
 def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=None, out=None, out_dtype=torch.bfloat16,
             alpha=1.0, row_group=0, rowadd=None, out_rows=None, colsum=None):
     """out[M,N] = epilogue(alpha * a[M,K] @ b[N,K]^T); see include/dclip.h:dclip_gemm_nt.
-    act='gelu_save' writes / act='mulaux' reads the 8-bit gelu' (uint8 [M,N]); out_dtype float16 = the teacher's fp16 residual stream
+    act='gelu_save' / 'quickgelu_save' write, act='mulaux' reads the 8-bit derivative (uint8 [M,N]); out_dtype float16 = the teacher's fp16 residual stream
     (residual then float16 too, act none)."""
     _chk(a, b, bias, aux_in, aux_out, residual, out, rowadd)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
@@ -39,7 +39,7 @@ def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=No
         out = torch.empty((rows, N), dtype=out_dtype, device=a.device)
     assert out.stride(1) == 1
     ldr = residual.stride(0) if residual is not None else 0
-    if act == 'gelu_save' and aux_out is not None:
+    if act in ('gelu_save', 'quickgelu_save') and aux_out is not None:
         assert aux_out.dtype == torch.uint8 and aux_out.stride(0) == out.stride(0)
     if act == 'mulaux':
         assert aux_in.dtype == torch.uint8 and aux_in.stride(0) == out.stride(0)

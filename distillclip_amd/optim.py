@@ -25,8 +25,14 @@ class FusedAdamW:
     Data-parallel runs (tower.dp set by parallel.GradSync.plan): each rank updates only its 1/W shard of every gradient bucket
     from the reduce-scattered average, keeps m / v for that shard only, and the updated parameters are all-gathered."""
 
-    def __init__(self, towers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, towers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, extra_params=()):
+        """extra_params: trainable parameters that live outside the towers' flat buffers — the embedding_projection / hidden_projection
+        linears of a plain CLIP encoder in the student role (reference image_encoder.py:23-25, text_encoder.py:45-47): four small tensors
+        whose gradients autograd produces; each gets its own dclip_adamw launch (after an all-reduce of its gradient in a data-parallel
+        run whose exchange this package owns)."""
         self.towers = list(towers)
+        self.extras = [p for p in extra_params if p.requires_grad]
+        self._extra_state = {}
         self.base_lr = self.lr = lr
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = 0
@@ -82,6 +88,8 @@ class FusedAdamW:
             if tw.flat_grad is not None and not getattr(tw, '_grad_clean', False):
                 self.join()
                 tw.flat_grad.zero_()
+        for p in self.extras:
+            p.grad = None
 
     @staticmethod
     def _pack_autograd_grads(tw):
@@ -216,11 +224,38 @@ class FusedAdamW:
                 joined.append(stream)
                 tw.opt_done = torch.cuda.Event()
                 tw.opt_done.record(stream)
+        self._step_extras(zero_grad, main)
         if join:
             for stream in joined:
                 main.wait_stream(stream)
             for tw in self.towers:
                 tw.opt_done = None
+
+    def _extra_moments(self, p):
+        st = self._extra_state.get(id(p))
+        if st is None:
+            st = self._extra_state[id(p)] = (torch.zeros(p.numel(), dtype=torch.float32, device=p.device),
+                                             torch.zeros(p.numel(), dtype=torch.float32, device=p.device))
+        return st
+
+    def _step_extras(self, zero_grad, main):
+        """the parameters outside the tower buffers, on the current stream (their gradients were written by autograd on it)"""
+        if not self.extras:
+            return
+        from .parallel import all_reduce_avg
+        sync = next((tw.sync for tw in self.towers if getattr(tw, 'sync', None) is not None), None)
+        items = []
+        for p in self.extras:
+            if p.grad is None:
+                continue                                  # torch.optim.AdamW skips parameters without a gradient
+            if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                raise RuntimeError('FusedAdamW: extra parameters and their gradients must be contiguous f32 tensors')
+            if sync is not None and sync.enabled:
+                all_reduce_avg(p.grad)
+            m, v = self._extra_moments(p)
+            items.append((p.data.view(-1), p.grad.view(-1), m, v))
+        if items:
+            self._adamw_many(items, zero_grad, main.cuda_stream if main is not None else None)
 
     def join(self):
         """order the current stream after every tower's pending (un-joined) update"""
@@ -252,6 +287,8 @@ class FusedAdamW:
             for p, off in zip(live, tw._offsets):
                 if any(a <= off < b for a, b in rng):        # the set captured at construction, not the live flags
                     where[p.data_ptr()] = (tw, off, p.numel(), tuple(p.shape))
+        for p in self.extras:
+            where[p.data_ptr()] = (p, None, p.numel(), tuple(p.shape))
         if params is None:
             return list(where.values())
         out = []
@@ -277,6 +314,12 @@ class FusedAdamW:
         state = {}
         full = {id(tw): self._full_moments(tw) for tw in self.towers if id(tw) in self._state}
         for i, (tw, off, n, shape) in enumerate(slots):
+            if off is None:                               # a parameter outside the tower buffers
+                if id(tw) in self._extra_state:
+                    m, v = self._extra_state[id(tw)]
+                    state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': m.view(shape).clone(),
+                                'exp_avg_sq': v.view(shape).clone()}
+                continue
             if id(tw) in full:
                 m, v = full[id(tw)]
                 state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': m[off:off + n].view(shape).clone(),
@@ -302,6 +345,12 @@ class FusedAdamW:
                 continue
             if tuple(st['exp_avg'].shape) != shape:
                 raise ValueError(f"FusedAdamW.load_state_dict: parameter {i} has shape {shape}, saved {tuple(st['exp_avg'].shape)}")
+            if off is None:                               # a parameter outside the tower buffers
+                m, v = self._extra_moments(tw)
+                m.copy_(st['exp_avg'].reshape(-1))
+                v.copy_(st['exp_avg_sq'].reshape(-1))
+                steps.add(int(float(st['step'])))
+                continue
             m, v = self._moments(tw)
             if self._sharded(tw):
                 # keep the slices of this parameter that fall into the shards this rank owns

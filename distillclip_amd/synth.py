@@ -129,6 +129,18 @@ def teacher_text_state(seed, width=512, layers=12, context_length=77, vocab_size
     return sd
 
 
+def clip_student_states(seed, width, layers, patch, resolution, context_length, vocab_size, out_dim, tea_width_image, tea_width_text):
+    """(image, text) state dicts of the reference's ImageEncoder(is_student=True) / TextEncoder(is_student=True): the CLIP tower's tensors
+    plus the two projection linears nn.Linear(width, tea_transformer_width) (image_encoder.py:23-25, text_encoder.py:45-47)."""
+    img = teacher_image_state(seed, width, layers, patch, resolution, out_dim)
+    txt = teacher_text_state(seed, width, layers, context_length, vocab_size, out_dim)
+    for tag, sd, tw in (('img', img, tea_width_image), ('txt', txt, tea_width_text)):
+        for name in ('embedding_projection', 'hidden_projection'):
+            sd[f'{name}.weight'] = normal(seed, f'{tag}.{name}.weight', (tw, width), width ** -0.5)
+            sd[f'{name}.bias'] = normal(seed, f'{tag}.{name}.bias', (tw,), 0.02)
+    return img, txt
+
+
 def _student_blocks(seed, sd, prefix, dim, n_blocks, heads, repeats, mlp_ratio, qkv_bias, use_transform):
     hid = int(dim * mlp_ratio)
     eye = np.eye(heads, dtype=np.float32)

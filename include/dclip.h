@@ -46,6 +46,8 @@ const char* dclip_last_error_string(void);  /* thread-local */
 #define DCLIP_ACT_DGELU 3     /* multiply by gelu'(aux_in): backward of DCLIP_ACT_GELU from the saved pre-activation */
 #define DCLIP_ACT_MULAUX 4    /* multiply by the 8-bit gelu' in aux_in: backward of DCLIP_ACT_GELU_SAVE */
 #define DCLIP_ACT_GELU_SAVE 5 /* DCLIP_ACT_GELU whose aux_out receives gelu'(pre-activation) as 8-bit fixed point (below) */
+#define DCLIP_ACT_QUICKGELU_SAVE 6 /* DCLIP_ACT_QUICKGELU with its derivative saved the same way: a CLIP tower that trains (plain
+                                      ImageEncoder / TextEncoder as student, reference image_encoder.py:23-25, text_encoder.py:45-47) */
 /* output dtype codes of dclip_gemm_nt / dclip_embed_gather / dclip_layernorm_fwd_f16 */
 #define DCLIP_OUT_BF16 0
 #define DCLIP_OUT_F32 1
@@ -60,7 +62,8 @@ const char* dclip_last_error_string(void);  /* thread-local */
  *   gelu'(pre-activation) in aux_out instead — ONE BYTE per element, uint8 [M,N] with ld = ldc bytes: code q = rint((g' + 0.13) * 255 / 1.26),
  *   value -0.13 + q * 1.26 / 255 (the derivative of the exact GELU lies in [-0.129, 1.129]; |error| <= 2.5e-3) — which
  *   DCLIP_ACT_MULAUX multiplies by: the training towers use that pair, the derivative being a few extra instructions in the
- *   forward epilogue and a single multiply in the backward one) ;
+ *   forward epilogue and a single multiply in the backward one; DCLIP_ACT_QUICKGELU_SAVE is the same pair for QuickGELU, whose
+ *   derivative s + 1.702 x s (1 - s), s = sigmoid(1.702 x), lies in [-0.1, 1.1]) ;
  *   + residual[M,N] (ld = ldr, may be NULL; f32 with bf16 / f32 output — may alias C when the output is f32 —, f16 with f16 output — may
  *   alias C) ; store C as bf16 / f32 / f16 (out_dtype = DCLIP_OUT_*; f16 needs act = DCLIP_ACT_NONE: the frozen teacher's in-place
  *   residual stream, reference _common.py:124-125 under `precision: 16`, config/final_config/l_clip.yaml:64).
@@ -309,7 +312,10 @@ int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, flo
 /* ---------------------------------------------------------------------------------------------------------------
  * Tower-level runtime: one call issues the whole launch sequence of an encoder tower on `stream`.
  *   teacher: reference model/component/_common.py:188-221 (VisionTransformer.forward) and
- *            model/component/text_encoder.py:62-92 (TextEncoder.encode_text) — inference only;
+ *            model/component/text_encoder.py:62-92 (TextEncoder.encode_text) — kind 0: frozen, inference only, fp16 residual stream;
+ *            kind 2: the same architecture and parameter order as a TRAINABLE tower — the plain ImageEncoder / TextEncoder in the
+ *            student role (reference image_encoder.py:16-25,54-59, text_encoder.py:41-47,75-80; their embedding_projection /
+ *            hidden_projection linears act on the exported hidden states and stay with the caller) — f32 residual stream, autograd of it;
  *   student: reference model/component/weight_share_model.py:336-372 / :482-512 (forward_features) and autograd of it.
  * The handle is an immutable host-side plan; params / grads / wcache / workspace are caller-owned device buffers.
  *
@@ -331,7 +337,8 @@ int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, flo
  * `grads` uses the same order; a NULL entry means "frozen, skip" (requires_grad = False).  Gradients ACCUMULATE (+=).
  */
 typedef struct dclip_encoder_cfg {
-    int32_t kind;        /* 0 teacher (CLIP residual blocks, QuickGELU), 1 student (weight-shared MiniViT blocks, erf GELU) */
+    int32_t kind;        /* 0 teacher (CLIP residual blocks, QuickGELU; frozen), 1 student (weight-shared MiniViT blocks, erf GELU),
+                          * 2 CLIP tower that trains (architecture and parameter order of kind 0, workspace / backward of kind 1) */
     int32_t modality;    /* 0 image, 1 text */
     int32_t tokens;      /* N: (resolution / patch)^2 + 1 for images, context_length for text */
     int32_t width;       /* D */
@@ -344,7 +351,7 @@ typedef struct dclip_encoder_cfg {
                                            * (grid = resolution / patch: 336 px at patch 32 reads the top-left 320 x 320) */
     int32_t vocab, embed_rank;            /* text only; embed_rank = embedding_compression_dim or 0 */
     int32_t head_mix;    /* use_transform: conv_l / conv_w cross-head mixing */
-    int32_t causal;      /* teacher text: 1 */
+    int32_t causal;      /* CLIP text towers: 1 */
 } dclip_encoder_cfg;
 
 typedef struct dclip_encoder dclip_encoder;
@@ -357,7 +364,7 @@ size_t dclip_encoder_workspace_bytes(const dclip_encoder* enc, int64_t B, int tr
 /* refresh the bf16 GEMM-weight cache from the f32 parameters (student: every step; teacher: once) */
 int dclip_encoder_prepare(const dclip_encoder* enc, const void* const* params, void* wcache, void* stream);
 /* input: image f32 [B,C,res,res] or token ids i64 [B,N].  last_representation: f32 [B,E] (class token / EOT row).
- * training = 1 keeps every activation backward needs inside `workspace` (student only).
+ * training = 1 keeps every activation backward needs inside `workspace` (kinds 1 and 2).
  * rep_out (nullable array of layers*repeats nullable f32 [B*N, D] pointers) / emb_out (nullable f32 [B*N, D]) receive the hidden
  * state after each block execution and the post-positional-embedding tokens (ControlOutput.need_rep / need_emb of the
  * reference, _loss.py:100-116); d_rep / d_emb are the matching gradients, added to the residual-stream gradient in backward.

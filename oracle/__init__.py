@@ -18,5 +18,6 @@ Exception: oracle/metrics.py (validation retrieval metrics) is 
 the reference computes top-k accuracy with torchmetrics, which this image lacks, so no reference-run golden exists.
 """
 from .encoders import (teacher_image_forward, teacher_text_forward, student_image_forward,   # noqa: F401
-                       student_text_forward, clip_forward, bf16_matched)
+                       student_text_forward, clip_forward, bf16_matched, clip_student_image_forward,
+                       clip_student_text_forward)
 from .loss import LossOracle, LOSS_FUNCS   # noqa: F401

@@ -94,6 +94,22 @@ def _gelu(z):
     return _GeluSave.apply(z) if _MATCHED else F.gelu(z)
 
 
+class _QuickGeluSave(torch.autograd.Function):
+    """c_fc epilogue of a CLIP tower that trains (include/dclip.h DCLIP_ACT_QUICKGELU_SAVE / DCLIP_ACT_MULAUX): u = bf16(z s(1.702 z)),
+    the derivative s + 1.702 z s (1 - s) saved as 8-bit fixed point, dz = bf16(du * derivative)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        sg = torch.sigmoid(1.702 * z)
+        ctx.save_for_backward(dg_quantise(sg + 1.702 * z * sg * (1.0 - sg)))
+        return _rb(z * sg)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dg,) = ctx.saved_tensors
+        return _rb(g * dg)
+
+
 def _lin(x, w, b=None, grad_operand=False):
     """F.linear with the bf16 weight cache; grad_operand: the output's gradient is a bf16 GEMM operand (bias added outside:
     bias gradients are column sums of the fp32 residual gradient)"""
@@ -115,7 +131,7 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-def _teacher_attention(h, sd, p, heads, mask, cap, tag):
+def _teacher_attention(h, sd, p, heads, mask, cap, tag, train=False):
     # reference _common.py:51-95
     B, N, D = h.shape
     hd = D // heads
@@ -126,7 +142,11 @@ def _teacher_attention(h, sd, p, heads, mask, cap, tag):
     scores = q @ k.transpose(-1, -2) / math.sqrt(hd)
     if mask is not None:
         scores = scores + mask
-    if _MATCHED:
+    if _MATCHED and train:
+        # a tower that trains runs the unfused kernels (scores f32 in memory, probabilities saved as bf16; the gradient of the scores
+        # enters the dQ / dK products as a bf16 operand), and the gradient of the out-projection's output is a bf16 GEMM operand
+        ctx = Q(Qb(scores).softmax(dim=-1)) @ v
+    elif _MATCHED:
         # the HIP kernel (attn_fused_fwd, round 5) keeps the probabilities UNNORMALISED in bf16 — e = exp(s - max), the row maximum exactly 1 —
         # and applies 1 / sum(e) (f32, over the unrounded e) to the value product: same arithmetic, the rounding point moved
         e = (scores - scores.amax(dim=-1, keepdim=True)).exp()
@@ -136,18 +156,20 @@ def _teacher_attention(h, sd, p, heads, mask, cap, tag):
     ctx = Q(ctx.permute(0, 2, 1, 3).reshape(B, N, D))
     if cap is not None:
         cap[tag + '.ctx'] = ctx
-    return _lin(ctx, sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'])
+    return _lin(ctx, sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'], grad_operand=train)
 
 
-def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, need_rep=False):
-    # reference _common.py:116-127 (block), :143-167 (stack)
+def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, need_rep=False, train=False):
+    # reference _common.py:116-127 (block), :143-167 (stack).  train: the tower is a student (f32 residual stream, saved activations)
     reps = []
+    Qs = (lambda t: t) if train else Qh
     for i in range(layers):
         p = f'{prefix}transformer.resblocks.{i}.'
-        x = Qh(x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}'))
+        x = Qs(x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}', train))
         h = Q(_ln(x, sd, p + 'ln_2'))
-        u = Q(quick_gelu(_lin(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'])))
-        x = Qh(x + _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias']))
+        z = _lin(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'])
+        u = _QuickGeluSave.apply(z) if (_MATCHED and train) else Q(quick_gelu(z))
+        x = Qs(x + _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'], grad_operand=train))
         if cap is not None:
             cap[f'tblock{i}.out'] = x
         if need_rep and (need_layers is None or i in need_layers):
@@ -155,20 +177,26 @@ def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, n
     return x, reps
 
 
-def teacher_image_forward(sd, image, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None):
-    """reference _common.py:188-221 (VisionTransformer.forward) behind image_encoder.py:50-65."""
+def teacher_image_forward(sd, image, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None, train=False):
+    """reference _common.py:188-221 (VisionTransformer.forward) behind image_encoder.py:50-65.  train: the encoder is the STUDENT
+    (image_encoder.py:16-25): same arithmetic with gradients; see clip_student_image_forward for its projection linears."""
     w = sd['visual.conv1.weight']
     width, patch = w.shape[0], w.shape[-1]
     layers = 1 + max(int(k.split('.')[3]) for k in sd if k.startswith('visual.transformer.resblocks.'))
     heads = heads or width // 64            # reference utils.py:126 (heads = width*32//64 // 32 ... = width//64)
+    Qs = (lambda t: t) if train else Qh
     x = F.conv2d(Qf(image), Qf(w), stride=patch)                    # :196
+    if train:
+        x = Qb(x)                                                   # (its gradient is the bf16 operand of the conv1 weight gradient)
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)      # :197-198
     cls = sd['visual.class_embedding'] + torch.zeros(x.shape[0], 1, width)
-    x = Qh(torch.cat([cls, x], dim=1) + sd['visual.positional_embedding'])   # :199-202
+    x = Qs(torch.cat([cls, x], dim=1) + sd['visual.positional_embedding'])   # :199-202
     emb = x if need_emb else None
-    x = Qh(_ln(x, sd, 'visual.ln_pre'))                              # :208
-    x, reps = _teacher_blocks(x, sd, 'visual.', layers, heads, None, cap, need_layers, need_rep)
+    x = Qs(_ln(x, sd, 'visual.ln_pre'))                              # :208
+    x, reps = _teacher_blocks(x, sd, 'visual.', layers, heads, None, cap, need_layers, need_rep, train)
     x = Q(_ln(x, sd, 'visual.ln_post')) @ Qf(sd['visual.proj'])      # :210-213
+    if train:
+        x = Qb(x)
     return dict(last_representation=x[:, 0, :], last_layer_output=x, representations=reps, embedding=emb)
 
 
@@ -177,17 +205,47 @@ def causal_mask(n):
     return torch.full((n, n), float('-inf')).triu_(1)
 
 
-def teacher_text_forward(sd, text, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None):
-    """reference text_encoder.py:62-92 (TextEncoder.encode_text)."""
+def teacher_text_forward(sd, text, heads=None, need_layers=None, need_rep=False, need_emb=False, cap=None, train=False):
+    """reference text_encoder.py:62-92 (TextEncoder.encode_text).  train: the encoder is the STUDENT (text_encoder.py:41-47)."""
     width = sd['positional_embedding'].shape[1]
     layers = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('transformer.resblocks.'))
     heads = heads or width // 64            # reference utils.py:94
-    x = Qh(sd['token_embedding.weight'][text] + sd['positional_embedding'])     # :65-66
+    x = sd['token_embedding.weight'][text] + sd['positional_embedding']        # :65-66
+    x = x if train else Qh(x)
     emb = x if need_emb else None
-    x, reps = _teacher_blocks(x, sd, '', layers, heads, causal_mask(text.shape[1]), cap, need_layers, need_rep)
+    x, reps = _teacher_blocks(x, sd, '', layers, heads, causal_mask(text.shape[1]), cap, need_layers, need_rep, train)
     x = Q(_ln(x, sd, 'ln_final')) @ Qf(sd['text_projection'])               # :69,72
+    if train:
+        x = Qb(x)
     pick = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]                 # :86
     return dict(last_representation=pick, last_layer_output=x, representations=reps, embedding=emb)
+
+
+def _project(t, sd, name):
+    """embedding_projection / hidden_projection of a CLIP encoder in the student role (nn.Linear on bf16 operands on the HIP path)"""
+    if not _MATCHED:
+        return F.linear(t, sd[name + '.weight'], sd[name + '.bias'])
+    return Qb(F.linear(Qf(t), Qf(sd[name + '.weight']))) + sd[name + '.bias']
+
+
+def _clip_student(out, sd, no_trans, need_rep, need_emb):
+    # reference image_encoder.py:54-59 / text_encoder.py:75-80
+    if not no_trans:
+        if need_rep:
+            out['representations'] = [_project(r, sd, 'hidden_projection') for r in out['representations']]
+        if need_emb:
+            out['embedding'] = _project(out['embedding'], sd, 'embedding_projection')
+    return out
+
+
+def clip_student_image_forward(sd, image, heads=None, need_rep=False, need_emb=False, no_trans=False, cap=None):
+    """reference image_encoder.py:50-65 with is_student=True: VisionTransformer + the two projection linears"""
+    return _clip_student(teacher_image_forward(sd, image, heads, None, need_rep, need_emb, cap, train=True), sd, no_trans, need_rep, need_emb)
+
+
+def clip_student_text_forward(sd, text, heads=None, need_rep=False, need_emb=False, no_trans=False, cap=None):
+    """reference text_encoder.py:62-92 with is_student=True"""
+    return _clip_student(teacher_text_forward(sd, text, heads, None, need_rep, need_emb, cap, train=True), sd, no_trans, need_rep, need_emb)
 
 
 def _mini_attention(h, sd, p, r, heads, use_transform, cap, tag):

@@ -50,6 +50,33 @@ def l336_inputs(g):
             T(synth.student_image_state(seed, **dict(S_IMG, img_size=336))), T(synth.student_text_state(seed, **S_TXT)))
 
 
+# plain CLIP encoders in the student role (tools/golden/gen_golden.py clip_student_tiny / clip_student_real)
+CLIPSTU_TINY = dict(res=32, patch=8, ctx=13, vocab=97, out_dim=64, width=128, layers=2, heads=2, tea_width=192, tea_layers=2, tea_heads=3,
+                    need_layers=None)
+CLIPSTU_REAL = dict(res=224, patch=32, ctx=77, vocab=49408, out_dim=512, width=512, layers=4, heads=8, tea_width=None, tea_layers=12,
+                    tea_heads=None, need_layers=[2, 5, 8, 11])
+CLIPSTU_LOSSES = ['out_l1', 'out_cos', 'cos_diff', 'hidden_rep_mse', 'embedding_mse']
+CLIPSTU_SMOOTH = ['out_cos', 'hidden_rep_mse', 'embedding_mse']
+
+
+def clipstu_inputs(g, c):
+    """-> image, text, teacher image state, teacher text state, student image state, student text state (the generator's recipe:
+    teacher from `seed`, students from `seed + 1`)"""
+    seed, B = int(g['seed']), int(g['B'])
+    if c is CLIPSTU_TINY:
+        image = torch.from_numpy(synth.images(seed, B, c['res']))
+        text = torch.from_numpy(synth.captions(seed, B, c['ctx'], c['vocab'], 3, 9))
+        tsd_i = T(synth.teacher_image_state(seed, c['tea_width'], c['tea_layers'], c['patch'], c['res'], c['out_dim']))
+        tsd_t = T(synth.teacher_text_state(seed, c['tea_width'], c['tea_layers'], c['ctx'], c['vocab'], c['out_dim']))
+        tw_i = tw_t = c['tea_width']
+    else:
+        image, text = torch.from_numpy(synth.images(seed, B, 224)), torch.from_numpy(synth.captions(seed, B))
+        tsd_i, tsd_t = T(synth.teacher_image_state(seed)), T(synth.teacher_text_state(seed))
+        tw_i, tw_t = 768, 512
+    sd_i, sd_t = synth.clip_student_states(seed + 1, c['width'], c['layers'], c['patch'], c['res'], c['ctx'], c['vocab'], c['out_dim'], tw_i, tw_t)
+    return image, text, tsd_i, tsd_t, T(sd_i), T(sd_t)
+
+
 def rel_l2(a, b):
     a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))

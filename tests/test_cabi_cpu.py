@@ -68,6 +68,14 @@ def test_argument_validation_happens_on_host():
         l.dclip_layernorm_fwd(16, 4, None, 16, 16, 16, 4, 0, None, None, 4, 2048, 1e-5, None)     # D > 1024
     with pytest.raises(ValueError, match='head dim'):
         l.dclip_attn_nt(16, 8, 16, 8, 16, 1, 1, 1, 8, 8, 48, 1.0, None)
+    import ctypes
+    one = lambda a: (ctypes.c_void_p * 1)(a)
+    with pytest.raises(ValueError, match='1..24'):
+        l.dclip_adamw_multi(one(16), one(16), one(16), one(16), (ctypes.c_int64 * 1)(64), 25, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None)
+    with pytest.raises(ValueError, match='multiple of 4'):
+        l.dclip_adamw_multi(one(16), one(16), one(16), one(16), (ctypes.c_int64 * 1)(66), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None)
+    with pytest.raises(ValueError, match='16-byte aligned'):
+        l.dclip_adamw_multi(one(16), one(24), one(16), one(16), (ctypes.c_int64 * 1)(64), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None)
     assert l.dclip_distill_loss_workspace(512, 512) > 6 * 512 * 512 * 4
 
 

@@ -352,3 +352,40 @@ def test_reduce_scatter_sharded_path_over_rccl_world1_equals_plain_path():
         #  such a near-zero-gradient element and only the +-lr-per-step bound holds)
         d = (plain[k] - sharded[k]).abs()
         assert d.max() < 3e-3 and d.mean() < (1e-3 if 'qkv.bias' in k else 2e-5), (k, d.max().item(), d.mean().item())
+
+
+def test_adamw_multi_range_launch_equals_one_launch_per_range():
+    """dclip_adamw_multi (round 5: the sharded data-parallel step updates the owned slice of every gradient bucket of a tower in ONE launch) gives
+    bit for bit what one dclip_adamw launch per range gives — ranges of very different lengths (a 64-element norm slice next to a 2.4 M-element
+    block slice), more ranges than one launch holds (24), gradients cleared when asked — and refuses misaligned / odd-length ranges on the host."""
+    import ctypes
+    from distillclip_amd._lib import lib
+    from distillclip_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    lens = [64, 2_359_296, 768, 4096, 1_769_472, 256] + [1024 * (1 + i % 5) for i in range(22)]          # 28 ranges -> two launches
+    mk = lambda: [torch.randn(n, device='cuda') for n in lens]
+    p0, g0, m0 = mk(), mk(), mk()
+    v0 = [t.abs() for t in mk()]
+
+    class _Tw:                       # the smallest thing FusedAdamW._adamw_many needs: it only looks at the tensors it is handed
+        flat = None
+    for zero in (False, True):
+        opt = FusedAdamW([], lr=3e-3, weight_decay=1e-2)
+        opt.step_count = 7
+        a = [[t.clone() for t in x] for x in (p0, g0, m0, v0)]
+        b = [[t.clone() for t in x] for x in (p0, g0, m0, v0)]
+        st = torch.cuda.current_stream().cuda_stream
+        opt._adamw_many(list(zip(*a)), zero, st)
+        for p, g, m, v in zip(*b):
+            opt._adamw(p, g, m, v, zero, st)
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            for t, u in zip(x, y):
+                assert torch.equal(t, u)
+        assert all((float(g.abs().max()) == 0.0) == zero for g in a[1])
+    one = torch.zeros(66, device='cuda')
+    arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+    with pytest.raises(ValueError, match='multiple of 4'):
+        lib().dclip_adamw_multi(arr(one), arr(one), arr(one), arr(one), (ctypes.c_int64 * 1)(66), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None)
+    with pytest.raises(ValueError, match='1..24'):
+        lib().dclip_adamw_multi(arr(one), arr(one), arr(one), arr(one), (ctypes.c_int64 * 1)(64), 25, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None)

@@ -95,8 +95,7 @@ def test_single_sample_cos_diff_is_nan_like_the_reference():
     assert torch.isnan(ref) and torch.isnan(loss)
 
 
-@pytest.mark.parametrize('B', [1, 3])
-def test_real_shapes_tiny_batch_forward(B):
+def test_real_shapes_tiny_batch_forward():
     """the shipped l_clip towers (ViT-B/32 teacher, 6x768/24h and 4x768/12h students) at B = 1 and 3: GEMM row counts of 50 / 77
     (below one tile) through every tower, embeddings against the oracle"""
     from distillclip_amd.model.component import (RepeatVisionTransformer, RepeatTextTransformer, ImageEncoder, TextEncoder)
@@ -113,16 +112,18 @@ def test_real_shapes_tiny_batch_forward(B):
     t_img.load_state_dict(sd_ti)
     t_txt = TextEncoder(512, 12, 8, 77, None, 49408, 512, is_student=False)
     t_txt.load_state_dict(sd_tt)
-    image = torch.from_numpy(synth.images(seed, B, 224))
-    text = torch.from_numpy(synth.captions(seed, B))
-    with torch.no_grad():
-        got = {'s_img': s_img.cuda()(image.cuda()).last_representation, 's_txt': s_txt.cuda()(text.cuda()).last_representation,
-               't_img': t_img.cuda()(image.cuda()).last_representation, 't_txt': t_txt.cuda()(text.cuda()).last_representation}
-        want = {'s_img': oracle.student_image_forward(sd_si, image, 24)['last_representation'],
-                's_txt': oracle.student_text_forward(sd_st, text, 12)['last_representation'],
-                't_img': oracle.teacher_image_forward(sd_ti, image)['last_representation'],
-                't_txt': oracle.teacher_text_forward(sd_tt, text)['last_representation']}
-    for k in got:
-        g, w = got[k].float().cpu(), want[k]
-        rel = ((g - w).norm() / w.norm()).item()
-        assert rel < 2e-2, (B, k, rel)
+    s_img, s_txt, t_img, t_txt = s_img.cuda(), s_txt.cuda(), t_img.cuda(), t_txt.cuda()
+    for B in (1, 3):
+        image = torch.from_numpy(synth.images(seed, B, 224))
+        text = torch.from_numpy(synth.captions(seed, B))
+        with torch.no_grad():
+            got = {'s_img': s_img(image.cuda()).last_representation, 's_txt': s_txt(text.cuda()).last_representation,
+                   't_img': t_img(image.cuda()).last_representation, 't_txt': t_txt(text.cuda()).last_representation}
+            want = {'s_img': oracle.student_image_forward(sd_si, image, 24)['last_representation'],
+                    's_txt': oracle.student_text_forward(sd_st, text, 12)['last_representation'],
+                    't_img': oracle.teacher_image_forward(sd_ti, image)['last_representation'],
+                    't_txt': oracle.teacher_text_forward(sd_tt, text)['last_representation']}
+        for k in got:
+            g, w = got[k].float().cpu(), want[k]
+            rel = ((g - w).norm() / w.norm()).item()
+            assert rel < 2e-2, (B, k, rel)

@@ -328,7 +328,7 @@ def test_gemm_nt_register_epilogue_variants(M, N, K):
 
 
 def test_random_shapes_gemm_attention_products_wgrad_layernorm():
-    """25 random shapes through gemm_nt (every epilogue the towers use), gemm_tn_acc, the attention products (row-major and quad-blocked
+    """16 random shapes through gemm_nt (every epilogue the towers use), gemm_tn_acc, the attention products (row-major and quad-blocked
     operand), the teacher's fused attention (causal and not) and LayerNorm forward, against torch fp32 on the same bf16 inputs, run-to-run
     equality included (tools/diag/kernel_fuzz.py; the fixed shape lists above cannot cover what a fuzz of the score stage found in round 3)."""
     import os
@@ -336,6 +336,6 @@ def test_random_shapes_gemm_attention_products_wgrad_layernorm():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     torch.cuda.synchronize()
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'diag', 'kernel_fuzz.py'), '25', '41'], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'diag', 'kernel_fuzz.py'), '16', '41'], capture_output=True, text=True,
                        timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

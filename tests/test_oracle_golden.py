@@ -322,6 +322,59 @@ def test_l_clip_336px_real_shapes_match_the_reference(golden_dir):
     _assert_grads(g, 'cos.s_txt', _grads(sdt), 44)
 
 
+def _clip_student_oracle(c, image, text, tsd_i, tsd_t, sd_i, sd_t, names, scale=None):
+    with torch.no_grad():
+        to = oracle.clip_forward(oracle.teacher_image_forward(tsd_i, image, c['tea_heads'], c['need_layers'], True, True),
+                                 oracle.teacher_text_forward(tsd_t, text, c['tea_heads'], c['need_layers'], True, True))
+    oi = oracle.clip_student_image_forward(sd_i, image, c['heads'], True, True)
+    ot = oracle.clip_student_text_forward(sd_t, text, c['heads'], True, True)
+    so = oracle.clip_forward(oi, ot)
+    loss, res = oracle.LossOracle(names, scale)(so, to, 'all')
+    return so, to, loss, res
+
+
+@pytest.mark.parametrize('case', ['tiny', 'real'])
+def test_plain_clip_encoders_as_students_match_the_reference(golden_dir, case):
+    """ImageEncoder / TextEncoder with is_student=True (reference image_encoder.py:16-25,54-59 ; text_encoder.py:41-47,75-80): the CLIP
+    architecture with gradients + embedding_projection / hidden_projection on the exported states, under a CLIP teacher pair; five loss
+    terms (the two feature-MSE terms read the projected states), then the gradient of EVERY parameter for the smooth objective."""
+    import real_cases as rc
+    c = rc.CLIPSTU_TINY if case == 'tiny' else rc.CLIPSTU_REAL
+    g = rc.load(golden_dir, 'clip_student_tiny.npz' if case == 'tiny' else 'real_b4_clipstu.npz')
+    image, text, tsd_i, tsd_t, sd_i, sd_t = rc.clipstu_inputs(g, c)
+    if case == 'tiny':
+        np.testing.assert_array_equal(image.numpy(), g['image'])
+        np.testing.assert_array_equal(text.numpy(), g['text'])
+    for v in list(sd_i.values()) + list(sd_t.values()):
+        v.requires_grad_(True)
+    so, to, loss, res = _clip_student_oracle(c, image, text, tsd_i, tsd_t, sd_i, sd_t, rc.CLIPSTU_LOSSES, {'cos_diff': 0.1})
+    for tag, o in (('s_img', so['visual_output']), ('s_txt', so['text_output']), ('t_img', to['visual_output']), ('t_txt', to['text_output'])):
+        close(o['last_representation'], g[f'{tag}.last_representation'], rtol=2e-4, atol=2e-5)
+        if case == 'tiny':
+            close(o['embedding'], g[f'{tag}.embedding'], rtol=2e-4, atol=2e-5)
+            assert len(o['representations']) == c['layers']
+            for i, r in enumerate(o['representations']):
+                close(r, g[f'{tag}.rep{i}'], rtol=2e-4, atol=5e-5)
+    close(loss, g['loss'], rtol=2e-5)
+    assert set(res) == {k[5:] for k in g if k.startswith('term.')}
+    for k in res:
+        close(res[k], g['term.' + k], rtol=2e-4, atol=1e-6)
+    so, to, loss2, res2 = _clip_student_oracle(c, image, text, tsd_i, tsd_t, sd_i, sd_t, rc.CLIPSTU_SMOOTH)
+    close(loss2, g['smooth.loss'], rtol=2e-5)
+    loss2.backward()
+    if case == 'tiny':
+        n = 0
+        for tag, sd in (('s_img', sd_i), ('s_txt', sd_t)):
+            for name, p in sd.items():
+                ref = g[f'smooth.{tag}.grad.{name}']
+                np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-3, atol=2e-4 * max(np.abs(ref).max(), 1e-12), err_msg=f'{tag}.{name}')
+                n += 1
+        assert n == len(sd_i) + len(sd_t) == (5 + 24 + 3 + 4) + (2 + 24 + 3 + 4)
+    else:
+        _assert_grads(g, 'smooth.s_img', _grads(sd_i), len(sd_i))
+        _assert_grads(g, 'smooth.s_txt', _grads(sd_t), len(sd_t))
+
+
 def test_metrics_known_answers():
     """validation metrics restatement (oracle/metrics.py) on hand-computable cases: a permutation structure fixes every
     rank, and the diagonal scores follow from the logits in closed form."""

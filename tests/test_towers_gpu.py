@@ -581,8 +581,9 @@ def test_unfused_score_stage_path_matches_the_same_goldens():
         pytest.skip('already inside a child test process')
     torch.cuda.synchronize()
     env = dict(os.environ, DCLIP_ATTN_MIX='0', DCLIP_TEST_CHILD='1')
-    # (tiny configuration: forward, training step, backward; real shapes: the every-parameter gradient golden and the matched oracle)
-    sel = 'tiny_forward_vs_reference_golden or tiny_dual_training_step or tiny_backward_vs_rounding_matched or real_shapes_b4_every or real_shapes_b4_backward'
+    # (tiny configuration: forward, training step, backward against the matched oracle; real shapes: the every-parameter gradient golden.
+    #  The unfused kernels are also what a trainable CLIP tower runs by default: tests/test_clip_student_gpu.py)
+    sel = 'tiny_forward_vs_reference_golden or tiny_dual_training_step or tiny_backward_vs_rounding_matched or real_shapes_b4_every'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', sel, '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

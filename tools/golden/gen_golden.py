@@ -536,6 +536,84 @@ def real_336():
     print('real_b4_336.npz', len(out), 'arrays', 'loss', float(loss))
 
 
+
+# ---- plain CLIP encoders in the student role (reference image_encoder.py:16-25,54-59 ; text_encoder.py:41-47,75-80) ------------------------
+def _clip_students(seed, width, layers, patch, res, ctx, vocab, out_dim, tea_width):
+    paras = dict(input_resolution=res, patch_size=patch, width=width, layers=layers, heads=width // 64, output_dim=out_dim,
+                 need_layers=None, drop_out=0.)
+    s_img = ImageEncoder(is_student=True, vit_paras=paras, tea_transformer_width=tea_width['img'])
+    s_txt = TextEncoder(transformer_width=width, transformer_layers=layers, transformer_heads=width // 64, context_length=ctx,
+                        need_layers=None, vocab_size=vocab, embed_dim=out_dim, tea_transformer_width=tea_width['txt'], is_student=True)
+    sd_i, sd_t = synth.clip_student_states(seed, width, layers, patch, res, ctx, vocab, out_dim, tea_width['img'], tea_width['txt'])
+    s_img.load_state_dict(T(sd_i))
+    s_txt.load_state_dict(T(sd_t))
+    return s_img.train(), s_txt.train()
+
+
+def _clip_student_case(out, s_img, s_txt, t_img, t_txt, image, text, full):
+    student, teacher = CLIPModel(True, s_img, s_txt, False), CLIPModel(False, t_img, t_txt, False)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    names = ['out_l1', 'out_cos', 'cos_diff', 'hidden_rep_mse', 'embedding_mse']
+    lc = quiet(LossCalculator, loss_name=names, loss_scale={'cos_diff': 0.1})
+    so = student(text, image, lc.get_control_output())
+    with torch.no_grad():
+        to = teacher(text, image, lc.get_control_output())
+    loss, res = lc(so, to, 'all')
+    out['loss'] = np_(loss)
+    for k, v in res.items():
+        out['term.' + k] = np_(v)
+    for tag, o in (('s_img', so.visual_output), ('s_txt', so.text_output), ('t_img', to.visual_output), ('t_txt', to.text_output)):
+        out[f'{tag}.last_representation'] = np_(o.last_representation)
+        if full:
+            out[f'{tag}.embedding'] = np_(o.embedding)
+            for i, r in enumerate(o.representations):
+                out[f'{tag}.rep{i}'] = np_(r)
+    # the smooth objective for the gradient comparison: cosine + both feature-MSE terms (every projection linear gets a gradient)
+    lc2 = quiet(LossCalculator, loss_name=['out_cos', 'hidden_rep_mse', 'embedding_mse'])
+    so = student(text, image, lc2.get_control_output())
+    loss2, res2 = lc2(so, to, 'all')
+    loss2.backward()
+    out['smooth.loss'] = np_(loss2)
+    for k, v in res2.items():
+        out['smooth.term.' + k] = np_(v)
+    if full:
+        out.update(grads_of(s_img, 'smooth.s_img.'))
+        out.update(grads_of(s_txt, 'smooth.s_txt.'))
+    else:
+        _every_gradient(out, 'smooth.s_img', s_img)
+        _every_gradient(out, 'smooth.s_txt', s_txt)
+
+
+def clip_student_tiny():
+    """ImageEncoder / TextEncoder with is_student=True (2 x 128, 2 heads) under a 2 x 192 teacher pair, B = 3: outputs, projected hidden
+    states and embeddings, every loss term, the gradient of every parameter (whole tensors)."""
+    seed, B, res, patch, ctx, vocab, E = 31, 3, 32, 8, 13, 97, 64
+    image = torch.from_numpy(synth.images(seed, B, res))
+    text = torch.from_numpy(synth.captions(seed, B, ctx, vocab, 3, 9))
+    t_img = build_teacher_image(seed, 192, 2, patch, res, E)
+    t_txt = build_teacher_text(seed, 192, 2, ctx, vocab, E)
+    s_img, s_txt = _clip_students(seed + 1, 128, 2, patch, res, ctx, vocab, E, {'img': 192, 'txt': 192})
+    out = {'seed': np.int64(seed), 'B': np.int64(B), 'image': np_(image), 'text': np_(text)}
+    _clip_student_case(out, s_img, s_txt, t_img, t_txt, image, text, full=True)
+    np.savez_compressed(os.path.join(OUT, 'clip_student_tiny.npz'), **out)
+    print('clip_student_tiny.npz', len(out), 'arrays', 'loss', float(out['loss']))
+
+
+def clip_student_real():
+    """the same pair at real shapes, B = 4: 4 x 512 (8 heads) CLIP students, patch 32 at 224 px / 77 tokens, under the ViT-B/32 teacher
+    pair with need_layers [2, 5, 8, 11]; gradient samples of every parameter."""
+    seed, B = 2026, 4
+    image = torch.from_numpy(synth.images(seed, B, 224))
+    text = torch.from_numpy(synth.captions(seed, B))
+    t_img = build_teacher_image(seed, 768, 12, 32, 224, 512, need_layers=[2, 5, 8, 11])
+    t_txt = build_teacher_text(seed, 512, 12, 77, 49408, 512, need_layers=[2, 5, 8, 11])
+    s_img, s_txt = _clip_students(seed + 1, 512, 4, 32, 224, 77, 49408, 512, {'img': 768, 'txt': 512})
+    out = {'seed': np.int64(seed), 'B': np.int64(B)}
+    _clip_student_case(out, s_img, s_txt, t_img, t_txt, image, text, full=False)
+    np.savez_compressed(os.path.join(OUT, 'real_b4_clipstu.npz'), **out)
+    print('real_b4_clipstu.npz', len(out), 'arrays', 'loss', float(out['loss']))
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['tiny', 'loss', 'real', 'trajectory']
@@ -555,3 +633,6 @@ if __name__ == '__main__':
         real_textc()
     if 'real_336' in which:
         real_336()
+    if 'clip_student' in which:
+        clip_student_tiny()
+        clip_student_real()
