@@ -218,3 +218,49 @@ def test_one_tower_image_student_with_frozen_embedding(golden_dir):
         assert torch.equal(after[k], before[k]), k
     assert not torch.equal(after['visual.transformer.resblocks.0.attn.in_proj_weight'], before['visual.transformer.resblocks.0.attn.in_proj_weight'])
     assert not torch.equal(after['visual.ln_pre.weight'], before['visual.ln_pre.weight'])
+
+
+@pytest.mark.parametrize('width,heads,res,patch,ctx,B', [(64, 1, 32, 8, 13, 1), (64, 2, 320, 32, 77, 2), (128, 4, 64, 8, 128, 2), (192, 3, 48, 16, 21, 5)])
+def test_edge_shapes_against_the_oracle(width, heads, res, patch, ctx, B):
+    """one head, head dim 32 and 64, 10 / 65 / 101 image tokens, 13 .. 128 causal text tokens, a single sample: forward and every gradient of
+    both trainable CLIP towers against the fp32 oracle (bf16 operand noise: <= 3e-2; 101 tokens = the 336 px grid of BASELINE config 5)"""
+    from distillclip_amd.model import LossCalculator
+    from distillclip_amd.model.component import ImageEncoder, TextEncoder
+    seed, vocab, E, layers = 100 + width + ctx, 211, 64, 2
+    sd_i, sd_t = synth.clip_student_states(seed, width, layers, patch, res, ctx, vocab, E, width, width)
+    sd_i, sd_t = rc.T(sd_i), rc.T(sd_t)
+    s_img = ImageEncoder(True, dict(input_resolution=res, patch_size=patch, width=width, layers=layers, heads=heads, output_dim=E), width)
+    s_txt = TextEncoder(width, layers, heads, ctx, None, vocab, E, tea_transformer_width=width, is_student=True)
+    s_img.load_state_dict(sd_i)
+    s_txt.load_state_dict(sd_t)
+    s_img, s_txt = s_img.cuda(), s_txt.cuda()
+    image = torch.from_numpy(synth.images(seed, B, res))
+    text = torch.from_numpy(synth.captions(seed, B, ctx, vocab, 3, ctx - 2))
+    target_i, target_t = torch.from_numpy(synth.normal(seed, 'ti', (B, E))), torch.from_numpy(synth.normal(seed, 'tt', (B, E)))
+    from distillclip_amd.model.component import ControlOutput
+    co = ControlOutput(need_rep=True, need_emb=True)
+    oi, ot = s_img(image.cuda(), co), s_txt(text.cuda(), co)
+    obj = lambda a, b, ti, tt: ((1 - torch.nn.functional.cosine_similarity(a['last_representation'], ti)).mean()
+                                + (1 - torch.nn.functional.cosine_similarity(b['last_representation'], tt)).mean()
+                                + sum(r.pow(2).mean() for r in a['representations']) + b['embedding'].pow(2).mean()
+                                + sum(r.pow(2).mean() for r in b['representations']) + a['embedding'].pow(2).mean())
+    as_dict = lambda o: dict(last_representation=o.last_representation, representations=o.representations, embedding=o.embedding)
+    loss = obj(as_dict(oi), as_dict(ot), target_i.cuda(), target_t.cuda())
+    loss.backward()
+    o_i = {k: v.clone().requires_grad_(True) for k, v in sd_i.items()}
+    o_t = {k: v.clone().requires_grad_(True) for k, v in sd_t.items()}
+    ri = oracle.clip_student_image_forward(o_i, image, heads, True, True, no_trans=s_img.no_trans)
+    rt = oracle.clip_student_text_forward(o_t, text, heads, True, True, no_trans=s_txt.no_trans)
+    ref = obj(ri, rt, target_i, target_t)
+    ref.backward()
+    assert rel_l2(oi.last_representation, ri['last_representation']) < 2e-2 and rel_l2(ot.last_representation, rt['last_representation']) < 2e-2
+    assert abs(loss.item() - ref.item()) <= 1e-2 * abs(ref.item()), (loss.item(), ref.item())
+    errs = {}
+    for tag, m, sd in (('img', s_img, o_i), ('txt', s_txt, o_t)):
+        for n, p in m.named_parameters():
+            if sd[n].grad is None:
+                assert p.grad is None, n               # (no_trans towers: text compares the layer count, so only the image projections rest)
+                continue
+            errs[f'{tag}.{n}'] = rel_l2(p.grad, sd[n].grad)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
