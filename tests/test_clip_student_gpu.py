@@ -220,9 +220,9 @@ def test_one_tower_image_student_with_frozen_embedding(golden_dir):
     assert not torch.equal(after['visual.ln_pre.weight'], before['visual.ln_pre.weight'])
 
 
-@pytest.mark.parametrize('width,heads,res,patch,ctx,B', [(64, 1, 32, 8, 13, 1), (64, 2, 320, 32, 77, 2), (128, 4, 64, 8, 128, 2), (192, 3, 48, 16, 21, 5)])
+@pytest.mark.parametrize('width,heads,res,patch,ctx,B', [(64, 1, 32, 8, 13, 1), (64, 2, 320, 32, 77, 2), (128, 4, 64, 8, 128, 2), (192, 3, 48, 16, 21, 5), (384, 6, 32, 16, 16, 1)])
 def test_edge_shapes_against_the_oracle(width, heads, res, patch, ctx, B):
-    """one head, head dim 32 and 64, 10 / 65 / 101 image tokens, 13 .. 128 causal text tokens, a single sample: forward and every gradient of
+    """one / three / six heads (the softmax kernels without head mixing take any count), head dim 32 and 64, 5 / 10 / 65 / 101 image tokens, 13 .. 128 causal text tokens, a single sample: forward and every gradient of
     both trainable CLIP towers against the fp32 oracle (bf16 operand noise: <= 3e-2; 101 tokens = the 336 px grid of BASELINE config 5)"""
     from distillclip_amd.model import LossCalculator
     from distillclip_amd.model.component import ImageEncoder, TextEncoder

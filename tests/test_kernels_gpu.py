@@ -124,7 +124,8 @@ def test_attention_products(B, N, H, hd):
 
 @pytest.mark.parametrize('B,N,H,mix,causal', [(3, 17, 4, True, False), (2, 13, 2, True, False), (4, 50, 24, True, False),
                                               (3, 77, 12, True, False), (3, 77, 8, False, True), (2, 50, 12, False, False),
-                                              (2, 101, 12, False, False)])
+                                              (2, 101, 12, False, False), (2, 21, 3, False, True), (3, 128, 1, False, True),
+                                              (2, 65, 6, False, False), (1, 50, 16, False, False)])
 def test_attention_softmax_stage(B, N, H, mix, causal):
     from distillclip_amd import ops
     Np = (N + 7) // 8 * 8
@@ -287,3 +288,22 @@ def test_multi_tensor_cast_transpose():
         assert torch.equal(b, w.bfloat16()) and torch.equal(t, w.bfloat16().t().contiguous())
     _, wt2 = ops.cast_transpose_multi(ws[:3], want_b=False)
     assert all(torch.equal(a, b) for a, b in zip(wt2, wt[:3]))
+
+
+@pytest.mark.parametrize('M,D', [(25600, 512), (39424, 768), (51, 1000), (3, 64), (4100, 1024)])
+def test_residual_gradient_add_with_column_sums(M, D):
+    """dclip_axpy_f32 (the hidden-state / embedding gradient entering the residual-stream gradient: dst += src, bf16 copy of dst, column sums of
+    src = the bias gradient of the linear that wrote the stream).  Round 5: the column sums are register partials + four atomics per thread
+    (they were one atomic per element); the add and the copy are exact, the sums within f32 summation-order noise."""
+    from distillclip_amd._lib import lib
+    torch.manual_seed(M + D)
+    dst, src = torch.randn(M, D, device='cuda'), torch.randn(M, D, device='cuda')
+    cs = torch.randn(D, device='cuda')
+    want_dst, want_cs = dst + src, cs.double() + src.double().sum(0)
+    copy = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    lib().dclip_axpy_f32(dst.data_ptr(), src.data_ptr(), copy.data_ptr(), M * D, cs.data_ptr(), D, st)
+    assert torch.equal(dst, want_dst) and torch.equal(copy, want_dst.bfloat16())
+    assert (cs.double() - want_cs).abs().max().item() <= 2e-5 * (M ** 0.5) + 1e-5
+    lib().dclip_axpy_f32(dst.data_ptr(), src.data_ptr(), None, M * D, None, D, st)           # no copy, no sums
+    assert torch.equal(dst, want_dst + src)

@@ -377,6 +377,62 @@ _S_TOTAL = 1024 + 128
 _S_BUCKETS = [(1024, 1152), (0, 1024)]              # a block bucket, then the embedding bucket: table [0, 960) + positions [960, 1024)
 
 
+def _extras_worker(rank, world, rdzv, q):
+    """parameters outside the tower buffers (the projection linears of a plain CLIP encoder in the student role): FusedAdamW averages their
+    autograd-owned gradients over the ranks before the update, and saves / restores their moments in torch's layout"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='file://' + rdzv, rank=rank, world_size=world)
+    from distillclip_amd.parallel import GradSync
+    from distillclip_amd.optim import FusedAdamW
+    FusedAdamW._adamw = _torch_adamw
+    tw = _FakeTower(_TOTAL, _BUCKETS, _TRAINABLE, seed=3)
+    g0 = torch.Generator().manual_seed(7)
+    extras = [torch.nn.Parameter(torch.randn(16, 8, generator=g0)), torch.nn.Parameter(torch.randn(16, generator=g0)),
+              torch.nn.Parameter(torch.randn(4, generator=g0), requires_grad=False)]
+    sync = GradSync()
+    sync.attach([tw])
+    opt = FusedAdamW([tw], lr=1e-2, weight_decay=1e-2, extra_params=extras)
+    assert len(opt.extras) == 2                                        # the frozen one never enters the optimizer
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        for i in range(len(_BUCKETS)):
+            sync.bucket_ready(tw, i)
+        sync.finish(tw)
+        for p in extras[:2]:
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        opt.zero_grad()
+        assert all(p.grad is None for p in extras)
+    sd = opt.state_dict()
+    opt2 = FusedAdamW([tw], lr=1.0, extra_params=extras)
+    opt2.load_state_dict(sd)
+    same = all(torch.equal(opt2._extra_state[id(p)][k], opt._extra_state[id(p)][k]) for p in extras[:2] for k in (0, 1))
+    q.put((rank, [p.detach().clone() for p in extras], len(sd['param_groups'][0]['params']), same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_extra_parameters_are_averaged_and_updated_like_torch_adamw_world2():
+    res = _run_ranks(_extras_worker, 2, timeout=240)
+    g0 = torch.Generator().manual_seed(7)
+    ref = [torch.nn.Parameter(torch.randn(16, 8, generator=g0)), torch.nn.Parameter(torch.randn(16, generator=g0))]
+    frozen = torch.randn(4, generator=g0)
+    topt = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    for step in range(3):
+        gens = [torch.Generator().manual_seed(100 * step + r) for r in range(2)]
+        for p in ref:
+            p.grad = sum(torch.randn(p.shape, generator=g) for g in gens) / 2
+        topt.step()
+    n_slots = None
+    for rank, got, n, same in res:
+        assert same
+        n_slots = n
+        for a, b in zip(got[:2], ref):
+            assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6), rank
+        assert torch.equal(got[2], frozen)
+    assert n_slots == 3 + 2                                            # the tower's three trainable segments + the two extras
+
+
 class _FakeTextTower(_FakeTower):
     def sparse_spec(self):
         return 1, 0, _SV, _SD
