@@ -515,148 +515,6 @@ __global__ __launch_bounds__(256, MAXJ <= 5 ? 2 : 1) void attn_tn_kernel(AttnMM 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dQ and dK of one (b, h) from ONE pass over dS (the gradient of the scaled scores):
-//     dQ[(b,i), h*HD + d] = alpha * sum_j dS[b,h,i,j] K[(b,j), h*HD + d]      (the NN product)
-//     dK[(b,j), h*HD + d] = alpha * sum_i dS[b,h,i,j] Q[(b,i), h*HD + d]      (the TN product)
-// attn_nn + attn_tn read dS twice (69 / 76 MB per block execution of the l_clip students); here a 32-query chunk of dS is staged once
-// (row-major in LDS whatever its layout in memory) and feeds both: transposing fragment reads for dK as in attn_tn_kernel, plain 16-byte
-// row reads for dQ against the wave's K tile as in attn_nn_kernel.  One wave per (b, h), MAXJ as in attn_tn_kernel.
-// ---------------------------------------------------------------------------------------------------------
-struct AttnDQK {
-    const void* dS; int64_t lda; int a_blocked;
-    const bf16_t* Q; const bf16_t* K; int64_t ldqk;     // token-major bf16 (the q and k thirds of the qkv rows)
-    bf16_t* dQ; bf16_t* dK; int64_t ldd;
-    int B, H, N, Np;
-    float alpha;
-};
-
-template <int HD, int MAXJ>
-__global__ __launch_bounds__(256, MAXJ <= 5 ? 2 : 1) void attn_dqk_kernel(AttnDQK p) {
-    constexpr int BROW = HD * 2 + 32;
-    constexpr int DT = HD / 16;
-    constexpr int AROW = MAXJ * 32 + 32;
-    constexpr int ACH = 32 * (MAXJ * 2) / 64, BCH = 32 * (HD / 8) / 64;
-    constexpr int KSM = (MAXJ + 1) / 2;             // 32-key steps of the dQ contraction
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nprob = p.B * p.H;
-    const int prob = min(blockIdx.x * 4 + wave, nprob - 1);
-    const bool live = blockIdx.x * 4 + wave < nprob;
-    const int b = prob / p.H, h = prob % p.H;
-    const int n32 = (p.N + 31) & ~31;
-    char* kt = smem + wave * (n32 * BROW + 32 * AROW + 32 * BROW);
-    char* at = kt + n32 * BROW;
-    char* bt = at + 32 * AROW;
-    const bf16_t* A = (const bf16_t*)p.dS + ((int64_t)b * p.H + h) * p.N * p.lda;
-    const bf16_t* Qm = p.Q + (int64_t)b * p.N * p.ldqk + h * HD;
-    const bf16_t* Km = p.K + (int64_t)b * p.N * p.ldqk + h * HD;
-    const int ntj = (p.N + 15) >> 4;
-    const int nchunk = (p.N + 31) >> 5, nks = n32 >> 5;
-    const int acpr = p.Np >> 3;
-    const int fr = lane & 15, fk = (lane >> 4) * 8;
-    f32x4 acc[MAXJ][DT];
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-#pragma unroll
-        for (int d = 0; d < DT; ++d) acc[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 ra[ACH], rb[BCH];
-    auto load_chunk = [&](int ch) {
-#pragma unroll
-        for (int k = 0; k < ACH; ++k) {
-            const int idx = k * 64 + lane;
-            const int r = p.a_blocked ? (idx & 31) : idx / acpr, c = p.a_blocked ? (idx >> 5) : idx - r * acpr;
-            ra[k] = u32x4{0u, 0u, 0u, 0u};
-            if (r < 32 && c < acpr && ch * 32 + r < p.N) ra[k] = load_a8(A, p.lda, p.N, p.a_blocked, ch * 32 + r, c * 8);
-        }
-#pragma unroll
-        for (int k = 0; k < BCH; ++k) {
-            const int idx = k * 64 + lane, r = idx / (HD / 8), c = idx % (HD / 8);
-            rb[k] = u32x4{0u, 0u, 0u, 0u};
-            if (ch * 32 + r < p.N) rb[k] = *(const u32x4*)(Qm + (int64_t)(ch * 32 + r) * p.ldqk + c * 8);
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int k = 0; k < ACH; ++k) {
-            const int idx = k * 64 + lane;
-            const int r = p.a_blocked ? (idx & 31) : idx / acpr, c = p.a_blocked ? (idx >> 5) : idx - r * acpr;
-            if (r < 32 && c < acpr) *(u32x4*)(at + r * AROW + c * 16) = ra[k];
-        }
-#pragma unroll
-        for (int k = 0; k < BCH; ++k) {
-            const int idx = k * 64 + lane, r = idx / (HD / 8), c = idx % (HD / 8);
-            const int q0 = 2 * c, q1 = 2 * c + 1;
-            *(u32x2*)(bt + r * BROW + (4 * (q0 % DT) + q0 / DT) * 8) = u32x2{rb[k][0], rb[k][1]};
-            *(u32x2*)(bt + r * BROW + (4 * (q1 % DT) + q1 / DT) * 8) = u32x2{rb[k][2], rb[k][3]};
-        }
-    };
-    load_chunk(0);                                   // (in flight while the K tile is staged)
-    wave_stage_perm4<BROW, DT>(Km, p.ldqk, p.N, n32, kt, lane);
-    for (int ch = 0; ch < nchunk; ++ch) {
-        __builtin_amdgcn_wave_barrier();
-        store_chunk();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (ch + 1 < nchunk) load_chunk(ch + 1);
-        // ---- dK += dS_chunk^T Q_chunk ----
-        bf16x8 bf[DT];
-#pragma unroll
-        for (int d = 0; d < DT; ++d) bf[d] = tr_frag<BROW>(bt, 0, d * 16, lane);
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            if (j < ntj) {
-                const bf16x8 af = tr_frag<AROW>(at, 0, j * 16, lane);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) acc[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[d], af, acc[j][d], 0, 0, 0);
-            }
-        }
-        // ---- dQ rows of this chunk = dS_chunk K (two 16-query tiles) ----
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int i = ch * 32 + t * 16 + fr;
-            if (ch * 32 + t * 16 < p.N) {             // (wave-uniform)
-                f32x4 dq[DT];
-#pragma unroll
-                for (int d = 0; d < DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KSM; ++ks) {
-                    if (ks < nks) {
-                        const int j0 = ks * 32 + fk;
-                        // columns >= Np of the staged chunk were never written: they stand for keys that do not exist
-                        const bf16x8 af = j0 < p.Np ? *(const bf16x8*)(at + (t * 16 + fr) * AROW + j0 * 2) : zero_frag();
-#pragma unroll
-                        for (int d = 0; d < DT; ++d)
-                            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<BROW>(kt, ks * 32, d * 16, lane), af, dq[d], 0, 0, 0);
-                    }
-                }
-                if (live && i < p.N) {
-                    bf16_t* o = p.dQ + ((int64_t)b * p.N + i) * p.ldd + h * HD + (lane >> 4) * (4 * DT);
-#pragma unroll
-                    for (int d = 0; d < DT; d += 2)
-                        *(bf16x8*)(o + d * 4) = bf16x8{f2bf(dq[d][0] * p.alpha), f2bf(dq[d][1] * p.alpha), f2bf(dq[d][2] * p.alpha), f2bf(dq[d][3] * p.alpha),
-                                                        f2bf(dq[d + 1][0] * p.alpha), f2bf(dq[d + 1][1] * p.alpha), f2bf(dq[d + 1][2] * p.alpha), f2bf(dq[d + 1][3] * p.alpha)};
-                }
-            }
-        }
-    }
-    if (live) {
-        bf16_t* C = p.dK + (int64_t)b * p.N * p.ldd + h * HD + (lane >> 4) * (4 * DT);
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < ntj) {
-                const int jj = j * 16 + (lane & 15);
-                if (jj < p.N) {
-                    bf16_t* o = C + (int64_t)jj * p.ldd;
-#pragma unroll
-                    for (int d = 0; d < DT; d += 2)
-                        *(bf16x8*)(o + d * 4) = bf16x8{f2bf(acc[j][d][0] * p.alpha), f2bf(acc[j][d][1] * p.alpha), f2bf(acc[j][d][2] * p.alpha), f2bf(acc[j][d][3] * p.alpha),
-                                                        f2bf(acc[j][d + 1][0] * p.alpha), f2bf(acc[j][d + 1][1] * p.alpha), f2bf(acc[j][d + 1][2] * p.alpha), f2bf(acc[j][d + 1][3] * p.alpha)};
-                }
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // softmax with optional cross-head mixes, one wave per (b, query row i); lane <-> key j (+64 per slot)
 //   A_g = sum_h Wl[g,h] S_h ; P_g = softmax_j(A_g) (causal: j <= i) ; R_g = sum_h Ww[g,h] P_h
 // ---------------------------------------------------------------------------------------------------------
@@ -1259,27 +1117,6 @@ extern "C" int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C
     else { if (ntile <= 4) TN_LAUNCH(64, 4); else if (ntile <= 5) TN_LAUNCH(64, 5); else TN_LAUNCH(64, 8); }
 #undef TN_LAUNCH
     return dclip_check_launch("dclip_attn_tn");
-}
-
-extern "C" int dclip_attn_dqk(const void* dS, const void* q, const void* k, int64_t ldqk, void* dq, void* dk, int64_t ldd, int64_t B, int64_t H,
-                              int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream) {
-    DCLIP_REQUIRE(dS && q && k && dq && dk && B > 0 && H > 0 && N > 0 && N <= NMAX, "dclip_attn_dqk: bad argument (N <= %d)", NMAX);
-    DCLIP_REQUIRE(hd == 32 || hd == 64, "dclip_attn_dqk: head dim must be 32 or 64 (got %ld)", (long)hd);
-    DCLIP_REQUIRE(Np == ((N + 7) & ~(int64_t)7) && ldqk % 8 == 0 && ldd % 8 == 0 && (((uintptr_t)dS | (uintptr_t)q | (uintptr_t)k | (uintptr_t)dq | (uintptr_t)dk) % 16) == 0,
-                  "dclip_attn_dqk: misaligned buffers (Np = round_up(N, 8), 16-byte aligned rows)");
-    AttnDQK p{dS, Np, a_blocked, (const bf16_t*)q, (const bf16_t*)k, ldqk, (bf16_t*)dq, (bf16_t*)dk, ldd, (int)B, (int)H, (int)N, (int)Np, alpha};
-    TraceScope tr(DCLIP_TRACE_ATTN, 4.0 * B * H * N * N * hd, 8.0 * B * H * N * hd + 2.0 * B * H * N * Np, stream, (int)(B * H), (int)N, (int)hd, 9);
-    const dim3 grid((unsigned)((B * H + 3) / 4));
-    hipStream_t st = (hipStream_t)stream;
-    const int ntile = ((int)Np + 15) / 16;
-    const int mj = ntile <= 4 ? 4 : (ntile <= 5 ? 5 : 8);
-    const size_t n32 = ((size_t)N + 31) & ~(size_t)31;
-    const size_t lds = (size_t)4 * ((n32 + 32) * ((size_t)hd * 2 + 32) + 32 * (mj * 32 + 32));
-#define DQK_LAUNCH(HDv, NTv) hipLaunchKernelGGL((attn_dqk_kernel<HDv, NTv>), grid, dim3(256), lds, st, p)
-    if (hd == 32) { if (ntile <= 4) DQK_LAUNCH(32, 4); else if (ntile <= 5) DQK_LAUNCH(32, 5); else DQK_LAUNCH(32, 8); }
-    else { if (ntile <= 4) DQK_LAUNCH(64, 4); else if (ntile <= 5) DQK_LAUNCH(64, 5); else DQK_LAUNCH(64, 8); }
-#undef DQK_LAUNCH
-    return dclip_check_launch("dclip_attn_dqk");
 }
 
 extern "C" int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t hd,

@@ -139,11 +139,6 @@ int dclip_attn_nn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t l
                   int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream);
 int dclip_attn_tn(const void* A, const void* Bm, int64_t ldb, void* C, int64_t ldc, int64_t B, int64_t H, int64_t N,
                   int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream);
-/* dqk : the nn and tn products of ONE score-gradient tensor in one pass over it (the backward of S = scale * q k^T:
- *       weight_share_model.py:101-103, _common.py:73-76):  dq[(b,i),h*hd+d] = alpha * sum_j dS[b,h,i,j] k[(b,j),h*hd+d]  and
- *       dk[(b,j),h*hd+d] = alpha * sum_i dS[b,h,i,j] q[(b,i),h*hd+d] ; q, k share the row stride ldqk, dq, dk the row stride ldd. */
-int dclip_attn_dqk(const void* dS, const void* q, const void* k, int64_t ldqk, void* dq, void* dk, int64_t ldd, int64_t B, int64_t H,
-                   int64_t N, int64_t Np, int64_t hd, float alpha, int a_blocked, void* stream);
 /* fused_fwd : ctx = softmax(scale * q k^T (+ causal mask)) v for plain multi-head attention (teacher, _common.py:73-89);
  *              qkv is the fused [B*N, 3*H*hd] projection ; scores / probabilities never reach HBM. */
 int dclip_attn_fused_fwd(const void* qkv, int64_t ldq, void* ctx, int64_t ldc, int64_t B, int64_t H, int64_t N, int64_t hd,
