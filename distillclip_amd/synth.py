@@ -43,20 +43,15 @@ def uniform(seed, name, n):
 
 
 _CHUNK = 1 << 18          # pairs per work item of a large tensor
-_POOL = None
 
 
-def _pool():
-    global _POOL
-    if _POOL is None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        try:
-            cpus = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cpus = os.cpu_count() or 1
-        _POOL = ThreadPoolExecutor(max(1, min(16, cpus)))
-    return _POOL
+def _workers():
+    import os
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    return max(1, min(16, cpus))
 
 
 def normal(seed, name, shape, std=1.0, mean=0.0):
@@ -79,7 +74,25 @@ def normal(seed, name, shape, std=1.0, mean=0.0):
     if m <= _CHUNK:
         piece(0, m)
     else:
-        list(_pool().map(lambda lo: piece(lo, min(lo + _CHUNK, m)), range(0, m, _CHUNK)))
+        # short-lived threads, joined before returning (no pool: nothing of this module is alive at interpreter exit)
+        import threading
+        starts = list(range(0, m, _CHUNK))
+        nw = min(_workers(), len(starts))
+        errors = []
+
+        def run(w):
+            try:
+                for lo in starts[w::nw]:
+                    piece(lo, min(lo + _CHUNK, m))
+            except BaseException as exc:      # re-raised on the calling thread
+                errors.append(exc)
+        threads = [threading.Thread(target=run, args=(w,), daemon=True) for w in range(nw)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
     return out.reshape(shape)
 
 
