@@ -358,27 +358,67 @@ __global__ __launch_bounds__(256) void adamw4_kernel(float4* __restrict__ p, flo
     }
 }
 
-// dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src into colsum (row length D).
-// With column sums the launch's stride (gridDim.x * 1024 elements) is a multiple of D, so a thread stays on its four columns: partial sums in
-// registers and four atomics per THREAD at the end (round 5; one atomic per ELEMENT before: 13 M atomics onto 512 addresses made the
-// hidden-state gradient add of a 25600 x 512 tensor a 3.2 ms launch).
-__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, bf16_t* __restrict__ dst_bf16,
-                                                   int64_t n, float* __restrict__ colsum, int D) {
-    const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+// dst += src (f32) ; optional bf16 copy of the updated dst.  Four independent 16-byte pieces per thread and trip: all their loads are in
+// flight before the first store.
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, bf16_t* __restrict__ dst_bf16, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += 4 * stride) {
+        float4 sv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) { sv[u] = *(const float4*)(src + i); dv[u] = *(const float4*)(dst + i); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                float4 d = dv[u];
+                d.x += sv[u].x; d.y += sv[u].y; d.z += sv[u].z; d.w += sv[u].w;
+                *(float4*)(dst + i) = d;
+                if (dst_bf16) *(bf16x4*)(dst_bf16 + i) = bf16x4{f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
+            }
+        }
+    }
+}
+
+// The same with column sums of src (row length D: the bias gradient of the linear that wrote the residual stream).  A block owns 256 columns
+// of a row range; thread (cg = tid & 63, rl = tid >> 6) walks rows r0 + rl, + 4, ... of its four columns with four rows in flight, the four
+// row lanes are combined through LDS: ONE atomic per column and block.  (Round 5.  Until then: one atomic per ELEMENT — 13 M atomics onto the
+// 16 cache lines of a 512-column sum made the hidden-state gradient add of a 25600 x 512 tensor a 3.2 ms launch — then four per thread of a
+// grid-stride loop, 0.5 M per launch, ~100 us: the same lines, contended by every CU.)
+__global__ __launch_bounds__(256) void axpy_colsum_kernel(float* __restrict__ dst, const float* __restrict__ src, bf16_t* __restrict__ dst_bf16,
+                                                          int M, int D, float* __restrict__ colsum, int rows_per_block) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + cg * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float4 part = float4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t i = first; i < n; i += (int64_t)gridDim.x * 1024) {
-        const float4 s = *(const float4*)(src + i);
-        float4 d = *(const float4*)(dst + i);
-        d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-        *(float4*)(dst + i) = d;
-        if (dst_bf16) *(bf16x4*)(dst_bf16 + i) = bf16x4{f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
-        part.x += s.x; part.y += s.y; part.z += s.z; part.w += s.w;
+    if (col < D) {
+        for (int r = r0 + rl; r < r1; r += 16) {
+            float4 sv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 4 * u < r1) {
+                    const int64_t i = (int64_t)(r + 4 * u) * D + col;
+                    sv[u] = *(const float4*)(src + i); dv[u] = *(const float4*)(dst + i);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 4 * u < r1) {
+                    const int64_t i = (int64_t)(r + 4 * u) * D + col;
+                    float4 d = dv[u];
+                    d.x += sv[u].x; d.y += sv[u].y; d.z += sv[u].z; d.w += sv[u].w;
+                    *(float4*)(dst + i) = d;
+                    if (dst_bf16) *(bf16x4*)(dst_bf16 + i) = bf16x4{f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
+                    part.x += sv[u].x; part.y += sv[u].y; part.z += sv[u].z; part.w += sv[u].w;
+                }
+        }
     }
-    if (colsum && first < n) {
-        const int c = (int)(first % D);
-        unsafeAtomicAdd(colsum + c, part.x); unsafeAtomicAdd(colsum + c + 1, part.y);
-        unsafeAtomicAdd(colsum + c + 2, part.z); unsafeAtomicAdd(colsum + c + 3, part.w);
-    }
+    red[rl][cg * 4] = part.x; red[rl][cg * 4 + 1] = part.y; red[rl][cg * 4 + 2] = part.z; red[rl][cg * 4 + 3] = part.w;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < D) unsafeAtomicAdd(colsum + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 inline int grid_for(int64_t work, int per_block = 256, int cap = 2048 * 4) {
@@ -582,17 +622,18 @@ extern "C" int dclip_adamw(float* p, float* g, float* m, float* v, int64_t n, fl
 
 extern "C" int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream) {
     DCLIP_REQUIRE(dst && src && n > 0 && n % 4 == 0 && D > 0 && D % 4 == 0, "dclip_axpy_f32: bad argument");
-    int grid = grid_for(n, 1024);
-    if (colsum_acc) {
-        // the grid's stride must be a multiple of the row length: blocks in multiples of D / gcd(D, 1024); ~2 blocks per CU keep the
-        // atomics at the end few (4 per thread)
-        int64_t a = D, b = 1024;
-        while (b) { const int64_t t = a % b; a = b; b = t; }
-        const int unit = (int)(D / a);
-        const int want = grid < 512 ? grid : 512;
-        grid = want <= unit ? unit : (want / unit) * unit;
+    if (!colsum_acc) {
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 4096, 2048)), dim3(256), 0, (hipStream_t)stream, dst, src, (bf16_t*)dst_bf16, n);
+        return dclip_check_launch("dclip_axpy_f32");
     }
-    hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, (bf16_t*)dst_bf16, n, colsum_acc, (int)D);
+    DCLIP_REQUIRE(n % D == 0 && n / D < (1LL << 31), "dclip_axpy_f32: column sums need whole rows (n %% D == 0)");
+    const int64_t M = n / D;
+    const int colblocks = (int)((D + 255) / 256);
+    // ~512 workgroups: enough rows in flight for the memory system, few enough atomics (256 per workgroup) onto the D sums
+    int rows_per_block = (int)((M * colblocks + 511) / 512);
+    rows_per_block = rows_per_block < 16 ? 16 : (rows_per_block + 15) & ~15;
+    const dim3 grid((unsigned)colblocks, (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    hipLaunchKernelGGL(axpy_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dst, src, (bf16_t*)dst_bf16, (int)M, (int)D, colsum_acc, rows_per_block);
     return dclip_check_launch("dclip_axpy_f32");
 }
 

@@ -558,27 +558,46 @@ extern "C" int dclip_distill_loss_rows(const float* s_img, const float* t_img, c
 //   acc[0] += coef * mean((s - t)^2) ; ds_acc += coef * 2 (s - t) / n      (ds_acc may be null)
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n, float coef,
                                                   float* __restrict__ acc, float* __restrict__ ds_acc) {
+    __shared__ float part[4];
     float sum = 0.f;
     const float k = coef * 2.f / (float)n;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-        const float4 x = *(const float4*)(s + i), y = *(const float4*)(t + i);
-        const float a0 = x.x - y.x, a1 = x.y - y.y, a2 = x.z - y.z, a3 = x.w - y.w;
-        sum += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        if (ds_acc) {
-            float4 g = *(const float4*)(ds_acc + i);
-            g.x += k * a0; g.y += k * a1; g.z += k * a2; g.w += k * a3;
-            *(float4*)(ds_acc + i) = g;
+    // four independent 16-byte pieces per thread and trip (their loads are all in flight before the first is consumed), one atomic per BLOCK
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += 4 * stride) {
+        float4 x[4], y[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                x[u] = *(const float4*)(s + i); y[u] = *(const float4*)(t + i);
+                if (ds_acc) g[u] = *(const float4*)(ds_acc + i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                const float a0 = x[u].x - y[u].x, a1 = x[u].y - y[u].y, a2 = x[u].z - y[u].z, a3 = x[u].w - y[u].w;
+                sum += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                if (ds_acc) {
+                    g[u].x += k * a0; g[u].y += k * a1; g[u].z += k * a2; g[u].w += k * a3;
+                    *(float4*)(ds_acc + i) = g[u];
+                }
+            }
         }
     }
     sum = wave_sum(sum);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(acc, sum * coef / (float)n);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(acc, ((part[0] + part[1]) + (part[2] + part[3])) * coef / (float)n);
 }
 
 extern "C" int dclip_feature_mse(const float* s, const float* t, int64_t n, float coef, float* loss_acc, float* ds_acc,
                                  void* stream) {
     DCLIP_REQUIRE(s && t && loss_acc && n > 0 && n % 4 == 0, "dclip_feature_mse: bad argument (n %% 4 == 0 required)");
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    int64_t blocks = (n / 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, t, n, coef, loss_acc, ds_acc);
     return dclip_check_launch("dclip_feature_mse");
 }

@@ -128,7 +128,8 @@ int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, const float* x
  * nn : C[(b,i),h*hd+d] = alpha * sum_j A[b,h,i,j] * Bm[(b,j),h*hd+d]          (O = R V ; dQ = dS K)
  * tn : C[(b,j),h*hd+d] = alpha * sum_i A[b,h,i,j] * Bm[(b,i),h*hd+d]          (dV = R^T dO ; dK = dS^T Q)
  * softmax_fwd : A_g = sum_h Wl[g,h] S_h ; P = softmax_j(A) (causal: j <= i) ; R_g = sum_h Ww[g,h] P_h.
- *               Wl/Ww NULL = plain multi-head softmax (teacher).  P (nullable) is saved for backward.
+ *               Wl/Ww NULL = plain multi-head softmax (CLIP towers; any head count — with mixing H must be 2, 4, 8, 12 or 24).
+ *               P (nullable) is saved for backward.
  * softmax_bwd : dS from dR (+ dWl, dWw += H x H weight gradients, f32).
  */
 int dclip_attn_nt(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int out_f32, int64_t B, int64_t H,
@@ -195,7 +196,7 @@ int dclip_attn_mix_bwd(const void* qkv, int64_t ld, const void* dO, int64_t ldo,
  */
 int dclip_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dclip_cast_f16_f32(const void* src, float* dst, int64_t n, void* stream);   /* f16 -> f32 (teacher hidden-state export) */
-/* dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src (row length D) */
+/* dst += src (f32) ; optional bf16 copy of the updated dst ; optional column sums of src (row length D; then n % D == 0) */
 int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int64_t n, float* colsum_acc, int64_t D, void* stream);
 int dclip_cast_transpose_bf16(const float* W, void* Wb, void* Wt, int64_t R, int64_t C, void* stream);
 /* n jobs of the above in one launch (per-step refresh of a student tower's bf16 weight cache): host arrays of device pointers

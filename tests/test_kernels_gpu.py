@@ -293,8 +293,8 @@ def test_multi_tensor_cast_transpose():
 @pytest.mark.parametrize('M,D', [(25600, 512), (39424, 768), (51, 1000), (3, 64), (4100, 1024)])
 def test_residual_gradient_add_with_column_sums(M, D):
     """dclip_axpy_f32 (the hidden-state / embedding gradient entering the residual-stream gradient: dst += src, bf16 copy of dst, column sums of
-    src = the bias gradient of the linear that wrote the stream).  Round 5: the column sums are register partials + four atomics per thread
-    (they were one atomic per element); the add and the copy are exact, the sums within f32 summation-order noise."""
+    src = the bias gradient of the linear that wrote the stream).  Round 5: a workgroup owns 256 columns of a row range and issues one atomic per
+    column (it was one atomic per element); the add and the copy are exact, the sums within f32 summation-order noise."""
     from distillclip_amd._lib import lib
     torch.manual_seed(M + D)
     dst, src = torch.randn(M, D, device='cuda'), torch.randn(M, D, device='cuda')
