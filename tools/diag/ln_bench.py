@@ -25,3 +25,5 @@ for M, D in [(25600, 768), (39424, 768), (39424, 512)]:
     print(f'bwd  {M:6d} {D:4d} {t*1e6:7.1f} us  {M*D*14/t/1e12:5.2f} TB/s  (x 4 + dy 2 + dx 4+4)')
     t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dx_bf16=dxb, dgamma=dg, dbeta=db, colsum=cs))
     print(f'bwd+ {M:6d} {D:4d} {t*1e6:7.1f} us  {M*D*16/t/1e12:5.2f} TB/s  (+ bf16 copy 2)')
+    t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dx_bf16=dxb))
+    print(f'bwd0 {M:6d} {D:4d} {t*1e6:7.1f} us  {M*D*16/t/1e12:5.2f} TB/s  (no dgamma / dbeta / column sums: the kernel without its closing atomics)')
