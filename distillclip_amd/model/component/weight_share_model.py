@@ -101,8 +101,12 @@ class _PatchEmbed(nn.Module):
 def _check_supported(repeated_times, rpe_config, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone=None,
                      qk_scale=None):
     if repeated_times < 2:
-        raise NotImplementedError('distillclip_amd implements the RepeatedMiniBlock layout (repeated_times >= 2), as used by '
-                                  'every shipped config')
+        # (the reference cannot run it either: with repeated_times = 1 its blocks are plain MiniBlocks, weight_share_model.py:283, whose
+        #  forward returns a TransformerLayerOutput, and forward_features reads `.last_layer_output` / `.representations` of it — :353-355 —
+        #  which that dataclass does not have, output.py:56-60)
+        raise NotImplementedError('repeated_times = 1 is not runnable in the reference (forward_features reads fields its MiniBlock output '
+                                  'lacks: weight_share_model.py:353, output.py:56); distillclip_amd implements the RepeatedMiniBlock layout '
+                                  '(repeated_times >= 2) every shipped config uses')
     if rpe_config is not None or hybrid_backbone is not None:
         raise NotImplementedError('iRPE / hybrid backbones are out of scope (rpe_config / hybrid_backbone are null in every '
                                   'shipped config)')
