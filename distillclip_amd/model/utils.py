@@ -22,6 +22,12 @@ _ARCH = {   # name -> (vision width, layers, patch, resolution, text width, text
 }
 
 
+def available_models():
+    """the archive names the reference knows (utils.py:18-28, :64-65).  Runnable on the HIP towers: ViT teachers of at most 128 tokens whose patch
+    has a multiple of 64 values (ViT-B/32, the teacher of every shipped config); ResNet teachers are out of scope."""
+    return ['RN50', 'RN101', 'RN50x4', 'RN50x16', 'RN50x64', 'ViT-B/32', 'ViT-B/16', 'ViT-L/14', 'ViT-L/14@336px']
+
+
 def get_transformer_para(sd):
     # reference utils.py:81-90
     return {'embed_dim': sd['text_projection'].shape[1], 'context_length': sd['positional_embedding'].shape[0],
