@@ -421,28 +421,6 @@ __global__ __launch_bounds__(256) void axpy_colsum_kernel(float* __restrict__ ds
     if (c < D) unsafeAtomicAdd(colsum + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-// LayerNorm folded into the linear that follows it (frozen weights: once per tower).  One wave per output row n of W [N, K]:
-//   Wf[n, k] = fp16(gamma[k] W[n, k]) ; c[n] = sum_k float(Wf[n, k]) (the ROUNDED weights: r (acc - mu c) is then exactly r sum_k (x_k - mu) Wf[n, k]) ;
-//   d[n] = sum_k beta[k] W[n, k] + bias[n]
-__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ bias, _Float16* __restrict__ Wf, float* __restrict__ c,
-                                                      float* __restrict__ d, int N, int K) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float cs = 0.f, ds = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-        const float4 w = *(const float4*)(W + (int64_t)n * K + k), g = *(const float4*)(gamma + k), b = *(const float4*)(beta + k);
-        const f16x4 h = {(_Float16)(g.x * w.x), (_Float16)(g.y * w.y), (_Float16)(g.z * w.z), (_Float16)(g.w * w.w)};
-        *(f16x4*)(Wf + (int64_t)n * K + k) = h;
-        cs += ((float)h[0] + (float)h[1]) + ((float)h[2] + (float)h[3]);
-        ds += (b.x * w.x + b.y * w.y) + (b.z * w.z + b.w * w.w);
-    }
-    cs = wave_sum(cs);
-    ds = wave_sum(ds);
-    if (lane == 0) { c[n] = cs; d[n] = ds + (bias ? bias[n] : 0.f); }
-}
-
 inline int grid_for(int64_t work, int per_block = 256, int cap = 2048 * 4) {
     int64_t g = (work + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -659,10 +637,3 @@ extern "C" int dclip_axpy_f32(float* dst, const float* src, void* dst_bf16, int6
     return dclip_check_launch("dclip_axpy_f32");
 }
 
-extern "C" int dclip_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* c, float* d, int64_t N,
-                                    int64_t K, void* stream) {
-    DCLIP_REQUIRE(W && gamma && beta && Wf && c && d && N > 0 && K > 0 && K % 4 == 0, "dclip_fold_layernorm: bad argument (K %% 4 == 0)");
-    DCLIP_REQUIRE((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) % 16) == 0 && ((uintptr_t)Wf % 8) == 0, "dclip_fold_layernorm: misaligned buffers");
-    hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, bias, (_Float16*)Wf, c, d, (int)N, (int)K);
-    return dclip_check_launch("dclip_fold_layernorm");
-}

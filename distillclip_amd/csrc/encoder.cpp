@@ -54,10 +54,7 @@ struct Plan {
     int p_final;                               // norm / ln_post .. projection
     int n_params;
     // weight cache offsets (bf16 elements), -1 = absent
-    struct BlockW {
-        int64_t qkv, qkv_t, proj, proj_t, fc1, fc1_t, fc2, fc2_t;
-        int64_t qkv_c, qkv_d, fc1_c, fc1_d;    // frozen teacher with folded LayerNorms: f32 vectors (offsets in bf16 elements), else -1
-    };
+    struct BlockW { int64_t qkv, qkv_t, proj, proj_t, fc1, fc1_t, fc2, fc2_t; };
     std::vector<BlockW> bw;
     int64_t w_embed, w_embed_t, w_head, w_head_t, w_total;
 };
@@ -111,10 +108,6 @@ bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
         b.qkv = wtake(off, 3 * D * D); b.proj = wtake(off, D * D); b.fc1 = wtake(off, F * D); b.fc2 = wtake(off, D * F);
         if (p.train) { b.qkv_t = wtake(off, 3 * D * D); b.proj_t = wtake(off, D * D); b.fc1_t = wtake(off, F * D); b.fc2_t = wtake(off, D * F); }
         else b.qkv_t = b.proj_t = b.fc1_t = b.fc2_t = -1;
-        b.qkv_c = b.qkv_d = b.fc1_c = b.fc1_d = -1;
-        if (!p.train) {   // (frozen) ln_1 / ln_2 folded into in_proj / c_fc: column sums and offsets, f32 = 2 cache elements each
-            b.qkv_c = wtake(off, 2 * 3 * D); b.qkv_d = wtake(off, 2 * 3 * D); b.fc1_c = wtake(off, 2 * F); b.fc1_d = wtake(off, 2 * F);
-        }
     }
     p.w_embed = p.w_embed_t = -1;
     if (p.image) p.w_embed = wtake(off, D * p.K);
@@ -123,13 +116,6 @@ bool make_plan(const dclip_encoder_cfg& c, Plan& p) {
     p.w_head_t = p.train ? wtake(off, E * D) : -1;                // [D, E]
     p.w_total = off;
     return true;
-}
-
-// The frozen teacher's ln_1 / ln_2 are folded into the GEMMs that consume them (dclip_gemm_ln_nt reads the fp16 residual stream itself; what
-// is left of each LayerNorm is a statistics pass).  DCLIP_LN_FOLD=0 keeps the LayerNorm kernels (bf16 rows through memory), the round-4 form.
-inline bool ln_fold(const Plan& p) {
-    static const int mode = [] { const char* e = getenv("DCLIP_LN_FOLD"); return e ? atoi(e) : 1; }();
-    return mode != 0 && !p.train;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -187,13 +173,12 @@ void layout(const Plan& p, int64_t B, bool training, void* base, Work& w, int64_
     if (!save) {
         xs = w.h16 ? (void*)b.take<_Float16>(M * D) : (void*)b.take<float>(M * D);
         shared.x_mid = xs;   // in-place residual stream
-        shared.h1 = ln_fold(p) ? nullptr : b.take<bf16_t>(M * D); shared.qkv = b.take<bf16_t>(M * 3 * D);
+        shared.h1 = b.take<bf16_t>(M * D); shared.qkv = b.take<bf16_t>(M * 3 * D);
         shared.S = b.take<float>(SN); shared.P = (p.student && p.c.head_mix) ? b.take<bf16_t>(SN) : nullptr;
         shared.Rm = b.take<bf16_t>(SN);
         shared.stats = b.take<float>(B * p.H * N);
         shared.ctx = b.take<bf16_t>(M * D); shared.h2 = shared.h1; shared.z = nullptr; shared.u = b.take<bf16_t>(M * F);
         shared.mean1 = shared.rstd1 = shared.mean2 = shared.rstd2 = nullptr;
-        if (ln_fold(p)) { shared.mean1 = shared.mean2 = b.take<float>(M); shared.rstd1 = shared.rstd2 = b.take<float>(M); }
     }
     for (int e = 0; e <= nex; ++e) w.X[e] = save ? (void*)b.take<float>(M * D) : xs;
     for (int e = 0; e < nex; ++e) {
@@ -363,18 +348,9 @@ extern "C" int dclip_encoder_prepare(const dclip_encoder* e, const void* const* 
         int iq, ip, i1, i2;
         if (p.student) { SB s = sblock(p, l); iq = s.qkvw; ip = s.prw; i1 = s.f1w; i2 = s.f2w; }
         else { TB t = tblock(p, l); iq = t.inw; ip = t.outw; i1 = t.fcw; i2 = t.prw; }
-        if (ln_fold(p)) {      // fp16(gamma o W) into the slots of the bf16 copies, + the two f32 vectors of each fold
-            const TB t = tblock(p, l);
-            for (int i : {t.ln1w, t.ln1b, t.inw, t.inb, t.ln2w, t.ln2b, t.fcw, t.fcb}) DCLIP_REQUIRE(params[i], "dclip_encoder_prepare: parameter %d missing", i);
-            CK(dclip_fold_layernorm(PF(params, t.inw), PF(params, t.ln1w), PF(params, t.ln1b), PF(params, t.inb), at(b.qkv), (float*)at(b.qkv_c),
-                                    (float*)at(b.qkv_d), 3 * D, D, st));
-            CK(dclip_fold_layernorm(PF(params, t.fcw), PF(params, t.ln2w), PF(params, t.ln2b), PF(params, t.fcb), at(b.fc1), (float*)at(b.fc1_c),
-                                    (float*)at(b.fc1_d), F, D, st));
-        } else {
-            job(PF(params, iq), at(b.qkv), at(b.qkv_t), 3 * D, D);
-            job(PF(params, i1), at(b.fc1), at(b.fc1_t), F, D);
-        }
+        job(PF(params, iq), at(b.qkv), at(b.qkv_t), 3 * D, D);
         job(PF(params, ip), at(b.proj), at(b.proj_t), D, D);
+        job(PF(params, i1), at(b.fc1), at(b.fc1_t), F, D);
         job(PF(params, i2), at(b.fc2), at(b.fc2_t), D, F);
     }
     if (p.image) job(PF(params, 0), at(p.w_embed), nullptr, D, p.K);                          // conv weight [D, C*p*p]
@@ -465,15 +441,8 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
         void* xin = w.X[ei];
         void* xout = w.X[ei + 1];
         const int sdt = w.h16 ? DCLIP_OUT_F16 : DCLIP_OUT_F32;        // dtype of the residual stream
-        const bool fold = ln_fold(p);
-        if (fold) {        // qkv = ln_1(x) W^T + b with the LayerNorm folded into the weights: the GEMM reads the fp16 stream itself
-            CK(dclip_row_stats_f16(xin, D, s.mean1, s.rstd1, M, D, 1e-5f, st));
-            CK(dclip_gemm_ln_nt(xin, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, (const float*)(W + bw.qkv_d), DCLIP_ACT_NONE, s.mean1, s.rstd1,
-                                (const float*)(W + bw.qkv_c), st));
-        } else {
-            CK(ln_stream(w.h16, xin, D, nullptr, n1w, n1b, s.h1, D, DCLIP_OUT_BF16, s.mean1, s.rstd1, M, D, st));
-            CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
-        }
+        CK(ln_stream(w.h16, xin, D, nullptr, n1w, n1b, s.h1, D, DCLIP_OUT_BF16, s.mean1, s.rstd1, M, D, st));
+        CK(gemm(s.h1, D, W + bw.qkv, D, s.qkv, 3 * D, M, 3 * D, D, bq, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, st));
         if (!training && !wl) {
             // inference without head mixing (the frozen teacher): one fused kernel, no score tensors in HBM
             CK(dclip_attn_fused_fwd(s.qkv, 3 * D, s.ctx, D, B, H, N, hd, scale, p.c.causal, st));
@@ -488,14 +457,8 @@ static int encoder_forward_impl(const dclip_encoder* e, const void* input, const
             }
         }
         CK(gemm(s.ctx, D, W + bw.proj, D, s.x_mid, D, M, D, D, bp, 0, nullptr, nullptr, xin, D, sdt, 0, nullptr, st));
-        if (fold) {
-            CK(dclip_row_stats_f16(s.x_mid, D, s.mean2, s.rstd2, M, D, 1e-5f, st));
-            CK(dclip_gemm_ln_nt(s.x_mid, D, W + bw.fc1, D, s.u, F, M, F, D, (const float*)(W + bw.fc1_d), DCLIP_ACT_QUICKGELU, s.mean2, s.rstd2,
-                                (const float*)(W + bw.fc1_c), st));
-        } else {
-            CK(ln_stream(w.h16, s.x_mid, D, nullptr, n2w, n2b, s.h2, D, DCLIP_OUT_BF16, s.mean2, s.rstd2, M, D, st));
-            CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : (s.z ? DCLIP_ACT_QUICKGELU_SAVE : DCLIP_ACT_QUICKGELU), nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
-        }
+        CK(ln_stream(w.h16, s.x_mid, D, nullptr, n2w, n2b, s.h2, D, DCLIP_OUT_BF16, s.mean2, s.rstd2, M, D, st));
+        CK(gemm(s.h2, D, W + bw.fc1, D, s.u, F, M, F, D, b1, p.student ? (s.z ? DCLIP_ACT_GELU_SAVE : DCLIP_ACT_GELU) : (s.z ? DCLIP_ACT_QUICKGELU_SAVE : DCLIP_ACT_QUICKGELU), nullptr, s.z, nullptr, 0, 0, 0, nullptr, st));
         CK(gemm(s.u, F, W + bw.fc2, F, xout, D, M, D, F, b2, 0, nullptr, nullptr, s.x_mid, D, sdt, 0, nullptr, st));
         // optional export of this execution's hidden state (ControlOutput.need_rep: _common.py:156-158, weight_share_model.py:211)
         if (rep_out && rep_out[ei]) CK(export_stream(w.h16, xout, rep_out[ei], M * D, st));

@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ G, int6
     }
 }
 
-template <int ACT, int OUT, bool FOLD = false>
+template <int ACT, int OUT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = mma<FOLD>(af[i], bfr[j], acc[i][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -128,10 +128,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             const float4 c0 = *(const float4*)(cs + rl * CLD + cc), c1 = *(const float4*)(cs + rl * CLD + cc + 4);
             v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
         }
-        if constexpr (!FOLD) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
         if (p.row_group > 0) {
             const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
             const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
@@ -144,8 +142,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, unused[8];
             GemmNT q = p;
             q.alpha = 1.f; q.row_group = 0; q.colsum = nullptr;        // (alpha, bias and the positional rows are applied above)
-            if constexpr (FOLD) epilogue_vec8<ACT, OUT, 0, true>(q, v, row, col, o, (int64_t)row * p.ldr + col, bias, unused, sd);
-            else epilogue_vec8<ACT, OUT, 0>(q, v, row, col, o, (int64_t)row * p.ldr + col, zero, unused, sd);
+            epilogue_vec8<ACT, OUT, 0>(q, v, row, col, o, (int64_t)row * p.ldr + col, zero, unused, sd);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
@@ -259,7 +256,7 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
-template <int ACT, int OUT, int MI, bool FOLD = false>
+template <int ACT, int OUT, int MI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RH = MI / 2;                      // row tiles per phase
@@ -372,10 +369,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             for (int i = 0; i < RH; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = mma<FOLD>(b0[j][kb], af[i][kb], acc[i][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][2 + j] = mma<FOLD>(b1[j][kb], af[i][kb], acc[i][2 + j]);
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[i][2 + j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
@@ -397,10 +394,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             for (int i = 0; i < RH; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[RH + i][j] = mma<FOLD>(b0[j][kb], af[i][kb], acc[RH + i][j]);
+                    acc[RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kb], af[i][kb], acc[RH + i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[RH + i][2 + j] = mma<FOLD>(b1[j][kb], af[i][kb], acc[RH + i][2 + j]);
+                    acc[RH + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kb], af[i][kb], acc[RH + i][2 + j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
@@ -428,16 +425,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
             const float4 q0 = *(const float4*)(p.bias + col), q1 = *(const float4*)(p.bias + col + 4);
             bias[jp][0] = q0.x; bias[jp][1] = q0.y; bias[jp][2] = q0.z; bias[jp][3] = q0.w;
             bias[jp][4] = q1.x; bias[jp][5] = q1.y; bias[jp][6] = q1.z; bias[jp][7] = q1.w;
-        }
-    }
-    // FOLD: this lane's row statistics (one row per row tile), all requested here, in front of the first unit (the main loop's fragment
-    // registers are dead); the 64 bytes of column sums per unit stay L1-resident loads (prefetching them as well spills at 320 rows)
-    float fmu[FOLD ? MI : 1], frs[FOLD ? MI : 1];
-    if constexpr (FOLD) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = min(m0c + wr * (MI * 16) + rl + i * 16, p.M - 1);
-            fmu[i] = p.row_mu[r]; frs[i] = p.row_rs[r];
         }
     }
     // units u = 2 i + jp, processed in batches of BU: a batch's side operands are all requested before its first store.  vmcnt
@@ -478,15 +465,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-                    if constexpr (FOLD) {
-                        FoldOps fo;
-                        fo.mu = fmu[i]; fo.rs = frs[i];
-                        epilogue_vec8<ACT, OUT, MODE, true>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
-                                                            side[SIDE ? u - ub : 0], &fo);
-                    } else {
-                        epilogue_vec8<ACT, OUT, MODE, false>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
-                                                             side[SIDE ? u - ub : 0]);
-                    }
+                    epilogue_vec8<ACT, OUT, MODE>(p, v, row, col, o0 + i * ostep + jp * 32, r0off + i * rstep + jp * 32, bias[jp], csum[jp],
+                                                      side[SIDE ? u - ub : 0]);
                 }
             }
         }
@@ -1097,7 +1077,7 @@ inline unsigned long long* next_clock_slot() {
     return buf + 4 * (g_clock_count.fetch_add(1, std::memory_order_relaxed) % cap);
 }
 
-template <int ACT, bool FOLD = false>
+template <int ACT>
 int launch_nt(GemmNT p, int out, hipStream_t st) {
     // OUT = 2 (f16 output + f16 in-place residual: the frozen teacher's residual stream) exists for the plain epilogue only
     if constexpr (ACT != 0) { if (out == 2) { dclip_set_error("dclip_gemm_nt: f16 output needs act = DCLIP_ACT_NONE"); return DCLIP_EINVAL; } }
@@ -1150,31 +1130,27 @@ int launch_nt(GemmNT p, int out, hipStream_t st) {
         }
         if (mi == 10) {
             const size_t lds320 = 2 * (2 * HT + 2 * 160 * BK * 2) + 16;
-            if constexpr (FOLD) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 10, true>), dim3(ntiles), dim3(512), lds320, st, p);
-            else if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
+            if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
             else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 10>), dim3(ntiles), dim3(512), lds320, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 10>), dim3(ntiles), dim3(512), lds320, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         if (mi == 6) {
             const size_t lds192 = 2 * (2 * HT + 2 * 96 * BK * 2) + 16;
-            if constexpr (FOLD) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 6, true>), dim3(ntiles), dim3(512), lds192, st, p);
-            else if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
+            if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
             else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 6>), dim3(ntiles), dim3(512), lds192, st, p); }
             else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 6>), dim3(ntiles), dim3(512), lds192, st, p);
             return dclip_check_launch("dclip_gemm_nt");
         }
         const size_t lds256 = 8 * HT + 16;
-        if constexpr (FOLD) hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 8, true>), dim3(ntiles), dim3(512), lds256, st, p);
-            else if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
+        if (out_f32) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 1, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
         else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt256_kernel<0, 2, 8>), dim3(ntiles), dim3(512), lds256, st, p); }
         else hipLaunchKernelGGL((gemm_nt256_kernel<ACT, 0, 8>), dim3(ntiles), dim3(512), lds256, st, p);
         return dclip_check_launch("dclip_gemm_nt");
     }
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NT_LDS;
-    if constexpr (FOLD) hipLaunchKernelGGL((gemm_nt_kernel<ACT, 0, true>), dim3(grid), dim3(256), lds, st, p);
-    else if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, 1>), dim3(grid), dim3(256), lds, st, p);
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<ACT, 1>), dim3(grid), dim3(256), lds, st, p);
     else if (out == 2) { if constexpr (ACT == 0) hipLaunchKernelGGL((gemm_nt_kernel<0, 2>), dim3(grid), dim3(256), lds, st, p); }
     else hipLaunchKernelGGL((gemm_nt_kernel<ACT, 0>), dim3(grid), dim3(256), lds, st, p);
     return dclip_check_launch("dclip_gemm_nt");
@@ -1222,7 +1198,6 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.stamps = g_gemm_stamps;
     p.group_n = 1 << 30;
     p.clk = nullptr;
-    p.row_mu = nullptr; p.row_rs = nullptr; p.col_c = nullptr;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes of the call: both operands once, the output once, plus what the fused epilogue consumes / produces — the f32 residual
     // it adds (read), the saved pre-activation / derivative it multiplies by (aux_in) or stores (aux_out); round 3 counted operands + output only
@@ -1241,30 +1216,6 @@ extern "C" int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
         case 5: return launch_nt<5>(p, out_dtype, st);
         default: return launch_nt<6>(p, out_dtype, st);
     }
-}
-
-extern "C" int dclip_gemm_ln_nt(const void* X, int64_t ldx, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                const float* d, int act, const float* row_mean, const float* row_rstd, const float* col_sum, void* stream) {
-    DCLIP_REQUIRE(X && Wf && C && d && row_mean && row_rstd && col_sum, "dclip_gemm_ln_nt: null operand");
-    DCLIP_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0, "dclip_gemm_ln_nt: need K %% %d == 0 (M=%ld N=%ld K=%ld)", BK, (long)M, (long)N, (long)K);
-    DCLIP_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && N % 8 == 0 && ldc % 8 == 0 && (((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)C | (uintptr_t)d | (uintptr_t)col_sum) % 16) == 0,
-                  "dclip_gemm_ln_nt: rows must be 16-byte aligned");
-    DCLIP_REQUIRE(act == DCLIP_ACT_NONE || act == DCLIP_ACT_QUICKGELU, "dclip_gemm_ln_nt: activation none or QuickGELU (got %d)", act);
-    DCLIP_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "dclip_gemm_ln_nt: dimension overflow");
-    GemmNT p;
-    p.A = (const bf16_t*)X; p.lda = ldx; p.B = (const bf16_t*)Wf; p.ldb = ldw; p.C = C; p.ldc = ldc;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = 1.f; p.bias = d;
-    p.aux_in = nullptr; p.aux_out = nullptr; p.residual = nullptr; p.ldr = 0;
-    p.row_group = 0; p.rowadd = nullptr; p.colsum = nullptr;
-    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
-    p.stamps = g_gemm_stamps;
-    p.group_n = 1 << 30;
-    p.clk = nullptr;
-    p.row_mu = row_mean; p.row_rs = row_rstd; p.col_c = col_sum;
-    TraceScope tr(DCLIP_TRACE_GEMM_NT, 2.0 * (double)M * (double)N * (double)K, 2.0 * ((double)M * K + (double)N * K) + 2.0 * (double)M * N + 8.0 * (double)M,
-                  stream, (int)M, (int)N, (int)K, act + 128);
-    if (act == DCLIP_ACT_QUICKGELU) return launch_nt<1, true>(p, 0, (hipStream_t)stream);
-    return launch_nt<0, true>(p, 0, (hipStream_t)stream);
 }
 
 // room for the partial tiles of the largest 256^2 wgrad launch (~one workgroup per CU, plus rounding)

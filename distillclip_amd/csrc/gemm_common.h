@@ -26,17 +26,7 @@ struct GemmNT {
     unsigned long long* stamps;                     // profiling only (dclip_trace_gemm_stamps): 6 x u64 per workgroup, else null
     int group_n;                                    // 256-/320-row kernels: column tiles per raster group (>= tiles_n: plain n-fastest)
     unsigned long long* clk;                        // measurement only (dclip_trace_gemm_clock): 4 x u64 of this launch, else null
-    // FOLD instantiations (dclip_gemm_ln_nt): A and B are fp16, the epilogue finishes a LayerNorm that was folded into B:
-    //   out = row_rs[m] * (acc - row_mu[m] * col_c[n]) + bias[n]
-    const float* row_mu; const float* row_rs; const float* col_c;
 };
-
-// one matrix-core step: bf16 operands, or (FOLD) the same 16-byte fragments read as fp16
-template <bool FOLD>
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    if constexpr (FOLD) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
 
 __device__ __forceinline__ int swz(int x) { return x ^ (((x >> 9) & 1) << 5); }
 
@@ -70,30 +60,13 @@ __device__ __forceinline__ void epilogue_load_side(const GemmNT& p, int64_t o, i
 // about 40 % of the issue slots of a plain bf16 epilogue, which is issue-bound).  MODE 1 / 2: the launch has no positional table, no
 // residual and no saved pre-activation (ACT 5 / 6 always save their derivative), without / with bias-gradient column sums — the
 // combinations the step's bf16 GEMMs use; the tests are compiled out.
-// the row / column operands of a FOLD epilogue, fetched by the caller ahead of the units that use them
-struct FoldOps { float mu, rs; };
-
-template <int ACT, int OUT, int MODE = 0, bool FOLD = false>
+template <int ACT, int OUT, int MODE = 0>
 __device__ __forceinline__ void epilogue_vec8(const GemmNT& p, float (&v)[8], int row, int col, int64_t o, int64_t orr,
-                                              const float (&bias)[8], float (&csum)[8], const EpiSide& sd, const FoldOps* fo = nullptr) {
+                                              const float (&bias)[8], float (&csum)[8], const EpiSide& sd) {
     constexpr bool LEAN = MODE != 0;            // MODE 3: f32 / f16 output with the (in-place) residual, nothing else optional
     // o = row * ldc + col, orr = row * ldr + col (formed incrementally by the caller)
-    if constexpr (FOLD) {
-        // the LayerNorm folded into the weights: acc = sum_k x_k W'_nk with W' = fp16(gamma o W); (x - mu) r . W' = r (acc - mu sum_k W'_nk)
-        float mu, rs, c[8];
-        if (fo) { mu = fo->mu; rs = fo->rs; }
-        else { mu = p.row_mu[row]; rs = p.row_rs[row]; }
-        {
-            const float4 c0 = *(const float4*)(p.col_c + col), c1 = *(const float4*)(p.col_c + col + 4);      // (L1-resident: the same 64 bytes for every row tile)
-            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
-        }
-        const float nm = -mu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(rs, fmaf(nm, c[e], v[e]), bias[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
-    }
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
     if (!LEAN && p.row_group > 0) {      // (patch-embedding GEMM only: the position-embedding rows, L2-resident)
         const float* ra = p.rowadd + (int64_t)(row % p.row_group) * p.N + col;
         const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);

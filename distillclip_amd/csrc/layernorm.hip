@@ -11,7 +11,7 @@ constexpr int LN_MAXV = 4;   // float4 chunks per lane: D <= 64 * 4 * 4 = 1024
 
 // X_F16: the rows are fp16 — the frozen teacher's residual stream, stored in the 16-bit type the reference's `precision: 16` autocast
 // keeps it in (_common.py:14-20: the custom LayerNorm computes in fp32 and returns the input's type); statistics stay f32
-template <int NV, int OUT, bool X_F16>      // OUT: 0 bf16, 1 f32, 2 f16, 3 none (row statistics only: dclip_row_stats_f16)
+template <int NV, int OUT, bool X_F16>      // OUT: 0 bf16, 1 f32, 2 f16
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, int64_t ldx, const int* __restrict__ ridx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      void* __restrict__ y, int64_t ldy, float* __restrict__ mean,
@@ -51,7 +51,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
         if (mean) mean[row] = mu;
         if (rstd) rstd[row] = rs;
     }
-    if constexpr (OUT == 3) return;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -259,19 +258,4 @@ extern "C" int dclip_layernorm_bwd(const void* dy, int64_t lddy, int dy_f32, con
         if (dy_f32) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(512), (size_t)3 * 8 * NV * 256 * 4, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D);
         else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(512), (size_t)3 * 8 * NV * 256 * 4, st, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dx_acc, lddx, (bf16_t*)dx_bf16, lddb, dgamma, dbeta, colsum_acc, (int)M, (int)D));
     return dclip_check_launch("dclip_layernorm_bwd");
-}
-
-// mean and 1 / sqrt(var + eps) of fp16 rows, nothing else: the frozen teacher's ln_1 / ln_2 are folded into the GEMMs that consume them
-// (dclip_gemm_ln_nt), which read the residual stream itself; what is left of the LayerNorm is this pass over the rows
-extern "C" int dclip_row_stats_f16(const void* x, int64_t ldx, float* mean, float* rstd, int64_t M, int64_t D, float eps, void* stream) {
-    DCLIP_REQUIRE(x && mean && rstd, "dclip_row_stats_f16: null operand");
-    DCLIP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "dclip_row_stats_f16: need 0 < D <= 1024, D %% 4 == 0 (D=%ld)", (long)D);
-    DCLIP_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 8) == 0, "dclip_row_stats_f16: row stride must be a multiple of 4, rows 8-byte aligned");
-    const int nv = (int)((D + 255) / 256);
-    const dim3 grid((unsigned)((M + 3) / 4));
-    hipStream_t st = (hipStream_t)stream;
-    TraceScope tr(DCLIP_TRACE_LAYERNORM, 4.0 * (double)M * D, (double)M * D * 2.0, stream);
-    LN_DISPATCH(nv, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3, true>), grid, dim3(256), 0, st, x, ldx, (const int*)nullptr, (const float*)nullptr,
-                                       (const float*)nullptr, (void*)nullptr, (int64_t)0, mean, rstd, (int)M, (int)D, eps));
-    return dclip_check_launch("dclip_row_stats_f16");
 }

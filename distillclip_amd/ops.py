@@ -51,37 +51,6 @@ def gemm_nt(a, b, *, bias=None, act=None, aux_in=None, aux_out=None, residual=No
     return out
 
 
-def fold_layernorm(w, gamma, beta, bias=None):
-    """-> (Wf fp16 [N,K], c f32 [N], d f32 [N]): a LayerNorm(gamma, beta) folded into the linear (w, bias) that consumes it (include/dclip.h)"""
-    _chk(w, gamma, beta, bias)
-    N, K = w.shape
-    wf = torch.empty((N, K), dtype=torch.float16, device=w.device)
-    c, d = torch.empty(N, dtype=torch.float32, device=w.device), torch.empty(N, dtype=torch.float32, device=w.device)
-    lib().dclip_fold_layernorm(_p(w.contiguous()), _p(gamma), _p(beta), _p(bias), _p(wf), _p(c), _p(d), N, K, _stream())
-    return wf, c, d
-
-
-def row_stats_f16(x, eps=1e-5):
-    """mean, rstd (f32 [M]) of the fp16 rows x [M, D]"""
-    _chk(x)
-    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1
-    M, D = x.shape
-    mean, rstd = torch.empty(M, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device)
-    lib().dclip_row_stats_f16(_p(x), x.stride(0), _p(mean), _p(rstd), M, D, eps, _stream())
-    return mean, rstd
-
-
-def gemm_ln_nt(x, wf, c, d, mean, rstd, act=None):
-    """bf16 [M,N] = act(rstd * (x @ wf^T - mean * c) + d): LN(x) @ W^T + b with the LayerNorm folded into wf (fold_layernorm), x the fp16 rows themselves"""
-    _chk(x, wf, c, d, mean, rstd)
-    assert x.dtype == torch.float16 and wf.dtype == torch.float16 and x.stride(1) == 1 and wf.stride(1) == 1
-    M, K = x.shape
-    N = wf.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    lib().dclip_gemm_ln_nt(_p(x), x.stride(0), _p(wf), wf.stride(0), _p(out), N, M, N, K, _p(d), ACT[act], _p(mean), _p(rstd), _p(c), _stream())
-    return out
-
-
 _TN_WS = {}
 
 

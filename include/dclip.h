@@ -78,23 +78,6 @@ int dclip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
                   int64_t row_group, const float* rowadd, float* colsum_acc, void* stream);
 
 /*
- * A LayerNorm folded into the linear that consumes it (the frozen teacher's ln_1 -> in_proj and ln_2 -> c_fc, reference _common.py:123-125:
- * x + attn(ln_1(x)), x + mlp(ln_2(x)); under `precision: 16` those linears run on fp16 operands):
- *   LN(x) W^T + b = r_m (x (gamma o W)^T - mu_m c_n) + d_n ,   c_n = sum_k Wf[n,k] ,   d_n = sum_k beta_k W[n,k] + b_n
- * dclip_fold_layernorm : once per (frozen) weight: Wf = fp16(gamma o W) [N,K], c[N] (f32 sum of the ROUNDED row, so that the identity above is exact
- *                        for what the matrix pipe computes), d[N].
- * dclip_row_stats_f16  : mean[m], rstd[m] of the fp16 rows x[M,D] (f32, eps inside the sqrt) — all that is left of the LayerNorm as a pass over memory.
- * dclip_gemm_ln_nt     : C[M,N] (bf16) = act(rstd[m] * (X[M,K] Wf[N,K]^T - mean[m] * c[n]) + d[n]) with X the fp16 residual stream itself and Wf fp16
- *                        (v_mfma_f32_16x16x32_f16, f32 accumulation); act = DCLIP_ACT_NONE or DCLIP_ACT_QUICKGELU.  The normalised rows never exist in memory.
- */
-int dclip_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* c, float* d, int64_t N, int64_t K,
-                         void* stream);
-int dclip_row_stats_f16(const void* x, int64_t ldx, float* mean, float* rstd, int64_t M, int64_t D, float eps, void* stream);
-int dclip_gemm_ln_nt(const void* X, int64_t ldx, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const float* d,
-                     int act, const float* row_mean, const float* row_rstd, const float* col_sum, void* stream);
-
-
-/*
  * dW[P,Q] (f32, ld = ldo) += sum_m A[m,P] * B[m,Q]         (weight gradient of nn.Linear: dY^T · X)
  *   autograd of the reference linears listed above (student only: weight_share_model.py:90,132,177,364).
  *   A bf16 [M,P] (lda), B bf16 [M,Q] (ldb).  P % 16 == 0, Q % 16 == 0.  Accumulates with f32 atomics

@@ -131,24 +131,11 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-def _ln_lin(x, sd, ln, w, b, train):
-    """linear(LayerNorm(x)) of a CLIP block (ln_1 -> in_proj, ln_2 -> c_fc).  Rounding-matched mode, frozen tower: the HIP path folds the
-    LayerNorm into the weights (include/dclip.h dclip_gemm_ln_nt) — the GEMM reads the fp16 stream itself against fp16(gamma o W), the row's
-    mean and 1/std enter in the f32 epilogue, beta W^T + b is an f32 vector: no rounding of the normalised rows at all."""
-    if not _MATCHED or train:
-        return _lin(Q(_ln(x, sd, ln)), w, b)
-    mu = x.mean(-1, keepdim=True)
-    rs = (x.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
-    wf = (sd[ln + '.weight'] * w).to(torch.float16).to(torch.float32)
-    return rs * ((x - mu) @ wf.t()) + (w @ sd[ln + '.bias'] + b)
-
-
-def _teacher_attention(qkv, sd, p, heads, mask, cap, tag, train=False):
-    # reference _common.py:51-95 (qkv: the in-projection of ln_1(x), made by the caller)
-    B, N, D3 = qkv.shape
-    D = D3 // 3
+def _teacher_attention(h, sd, p, heads, mask, cap, tag, train=False):
+    # reference _common.py:51-95
+    B, N, D = h.shape
     hd = D // heads
-    qkv = Q(qkv)
+    qkv = Q(_lin(h, sd[p + 'in_proj_weight'], sd[p + 'in_proj_bias']))
     q, k, v = qkv.chunk(3, dim=-1)
     sp = lambda t: t.view(B, N, heads, hd).permute(0, 2, 1, 3)
     q, k, v = sp(q), sp(k), sp(v)
@@ -178,9 +165,9 @@ def _teacher_blocks(x, sd, prefix, layers, heads, mask, cap, need_layers=None, n
     Qs = (lambda t: t) if train else Qh
     for i in range(layers):
         p = f'{prefix}transformer.resblocks.{i}.'
-        qkv = _ln_lin(x, sd, p + 'ln_1', sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias'], train)
-        x = Qs(x + _teacher_attention(qkv, sd, p + 'attn.', heads, mask, cap, f'tblock{i}', train))
-        z = _ln_lin(x, sd, p + 'ln_2', sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'], train)
+        x = Qs(x + _teacher_attention(Q(_ln(x, sd, p + 'ln_1')), sd, p + 'attn.', heads, mask, cap, f'tblock{i}', train))
+        h = Q(_ln(x, sd, p + 'ln_2'))
+        z = _lin(h, sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'])
         u = _QuickGeluSave.apply(z) if (_MATCHED and train) else Q(quick_gelu(z))
         x = Qs(x + _lin(u, sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'], grad_operand=train))
         if cap is not None:

@@ -339,38 +339,3 @@ def test_random_shapes_gemm_attention_products_wgrad_layernorm():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'diag', 'kernel_fuzz.py'), '16', '41'], capture_output=True, text=True,
                        timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize('M,N,K,act', [(25600, 2304, 768, None), (39424, 2048, 512, 'quickgelu'), (25600, 3072, 768, 'quickgelu'), (51, 136, 128, None),
-                                        (300, 384, 64, 'quickgelu'), (12800, 768, 768, None), (1030, 264, 1024, None)])
-def test_layernorm_folded_into_the_consuming_gemm(M, N, K, act):
-    """dclip_fold_layernorm + dclip_row_stats_f16 + dclip_gemm_ln_nt (round 5: the frozen teacher's ln_1 -> in_proj and ln_2 -> c_fc, reference
-    _common.py:123-125) = act(LayerNorm(x) W^T + b) on fp16 rows with a per-row offset and a few large channels (what a residual stream looks
-    like).  Against fp32 torch on the same fp16 rows: the only roundings are fp16(gamma o W) and the bf16 store (rel-L2 <= 4e-3); against the
-    same arithmetic on the folded weights: <= 3e-3 (the store)."""
-    from distillclip_amd import ops
-    g = torch.Generator(device='cuda').manual_seed(M + N + K)
-    x = torch.randn(M, K, device='cuda', generator=g) * 0.7 + torch.randn(M, 1, device='cuda', generator=g) * 2.0
-    x[:, 3] += 40.0
-    x[:, K // 2] -= 25.0
-    x = x.to(torch.float16)
-    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
-    bias = torch.randn(N, device='cuda', generator=g) * 0.1
-    gamma = 1.0 + 0.3 * torch.randn(K, device='cuda', generator=g)
-    beta = 0.1 * torch.randn(K, device='cuda', generator=g)
-    wf, c, d = ops.fold_layernorm(w, gamma, beta, bias)
-    mean, rstd = ops.row_stats_f16(x)
-    out = ops.gemm_ln_nt(x, wf, c, d, mean, rstd, act=act).float()
-    xf = x.float()
-    fn = (lambda t: t * torch.sigmoid(1.702 * t)) if act else (lambda t: t)
-    ref = fn(torch.nn.functional.linear(torch.nn.functional.layer_norm(xf, (K,), gamma, beta, 1e-5), w, bias))
-    mu, var = xf.mean(1), xf.var(1, unbiased=False)
-    assert (mean - mu).abs().max().item() <= 1e-4 * max(1.0, mu.abs().max().item())
-    assert ((rstd - (var + 1e-5).rsqrt()) / (var + 1e-5).rsqrt()).abs().max().item() <= 1e-4
-    assert torch.equal(wf, (gamma * w).to(torch.float16))
-    assert (c - wf.float().sum(1)).abs().max().item() <= 1e-4 * K ** 0.5 and (d - (w @ beta + bias)).abs().max().item() <= 1e-5 * K ** 0.5
-    mirror = fn(((xf - mu[:, None]) * (var + 1e-5).rsqrt()[:, None]) @ wf.float().t() + d)
-    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
-    assert rel(out, mirror) <= 3e-3, rel(out, mirror)
-    assert rel(out, ref) <= 4e-3, rel(out, ref)
-    assert torch.isfinite(out).all()
